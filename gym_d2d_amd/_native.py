@@ -1,0 +1,267 @@
+"""ctypes binding of libd2d_hip.so (include/d2d_hip.h).  There is no CPU fallback: if the library or a
+gfx950 GPU is missing, the calls below raise."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libd2d_hip.so'
+ABI_VERSION = 1
+MAX_LINKS = 2048
+
+# d2d_status
+OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+# d2d_link_type
+UPLINK, DOWNLINK, SIDELINK = 1, 2, 3
+# d2d_reward_fn
+REWARD_NONE, REWARD_SYSTEM_CAPACITY, REWARD_SHANNON, REWARD_CUE_SINR_SHANNON = 0, 1, 2, 3
+# d2d_obs_mode
+OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
+# d2d_buffer
+(BUF_POS_X, BUF_POS_Y, BUF_ACTIONS, BUF_RB, BUF_PWR, BUF_SINR_DB, BUF_SNR_DB, BUF_RATE_BPS, BUF_CAPACITY,
+ BUF_REWARD, BUF_OBS_TABLE, BUF_OBS, BUF_ENV_FLAGS, BUF_COUNT) = range(14)
+FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
+TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP = 0, 1, 2
+
+BUFFER_DTYPES = {BUF_ACTIONS: np.int32, BUF_RB: np.int32, BUF_PWR: np.int32, BUF_ENV_FLAGS: np.int32}
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ('abi_version', C.c_int32), ('device_ordinal', C.c_int32), ('num_envs', C.c_int32),
+        ('num_rbs', C.c_int32), ('num_cues', C.c_int32), ('num_due_pairs', C.c_int32),
+        ('max_links', C.c_int32), ('pwr_levels_due', C.c_int32), ('pwr_levels_cue', C.c_int32),
+        ('pwr_levels_mbs', C.c_int32), ('cell_radius_m', C.c_float), ('d2d_radius_m', C.c_float),
+    ]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f'libd2d_hip error {code}: {message}')
+        self.code = code
+        self.message = message
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_DP = C.POINTER(C.c_double)
+_FP = C.POINTER(C.c_float)
+_IP = C.POINTER(C.c_int32)
+
+# every symbol include/d2d_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'd2d_create': (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    'd2d_destroy': (C.c_int, [_P]),
+    'd2d_last_error': (C.c_char_p, []),
+    'd2d_abi_version': (C.c_int, []),
+    'd2d_set_stream': (C.c_int, [_P, _P]),
+    'd2d_synchronize': (C.c_int, [_P]),
+    'd2d_set_device_table': (C.c_int, [_P, _I, _DP, _DP, _DP, _DP, _DP]),
+    'd2d_set_path_loss_power_law': (C.c_int, [_P, _I, _DP, _DP, _DP]),
+    'd2d_set_path_loss_table': (C.c_int, [_P, _FP, _I]),
+    'd2d_set_links': (C.c_int, [_P, _I, _IP, _IP, _IP]),
+    'd2d_set_reward': (C.c_int, [_P, _I, C.c_float]),
+    'd2d_set_obs_mode': (C.c_int, [_P, _I]),
+    'd2d_set_bucketing': (C.c_int, [_P, _I]),
+    'd2d_set_tuning': (C.c_int, [_P, _I, _I]),
+    'd2d_get_buffer': (C.c_int, [_P, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    'd2d_bind_buffer': (C.c_int, [_P, _I, _P, C.c_size_t]),
+    'd2d_upload': (C.c_int, [_P, _I, _P, C.c_size_t, C.c_size_t]),
+    'd2d_download': (C.c_int, [_P, _I, _P, C.c_size_t, C.c_size_t]),
+    'd2d_set_positions': (C.c_int, [_P, _FP, _FP, _I, _I]),
+    'd2d_reset_positions': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), _FP]),
+    'd2d_set_env_offset': (C.c_int, [_P, C.c_uint64]),
+    'd2d_step': (C.c_int, [_P, _P]),
+    'd2d_step_rb_pwr': (C.c_int, [_P, _P, _P]),
+    'd2d_status_flags': (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    'd2d_profile_enable': (C.c_int, [_P, _I]),
+    'd2d_profile_read': (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'd2d_profile_reset': (C.c_int, [_P]),
+    'd2d_probe_write_bandwidth': (C.c_int, [_P, C.c_size_t, _I, C.POINTER(C.c_double)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree library and type every entry point.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f'{LIB_PATH} is missing - build it with `python -m gym_d2d_amd.build` '
+                          '(gym_d2d_amd has no CPU fallback for the simulation path)')
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.d2d_abi_version() != ABI_VERSION:
+        raise ImportError('libd2d_hip.so ABI version mismatch - rebuild it')
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != OK:
+        raise NativeError(rc, load_library().d2d_last_error().decode(errors='replace'))
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(_DP)
+
+
+class Handle:
+    """Thin RAII wrapper over d2d_handle*.  Array arguments are NumPy (host) unless named *_ptr (device)."""
+
+    def __init__(self, *, num_envs: int, num_rbs: int, num_cues: int, num_due_pairs: int, pwr_levels_due: int,
+                 pwr_levels_cue: int, pwr_levels_mbs: int, max_links: int = 0, device_ordinal: int = 0,
+                 cell_radius_m: float = 500.0, d2d_radius_m: float = 20.0):
+        self._lib = load_library()
+        self._h = _P()
+        cfg = Config(ABI_VERSION, device_ordinal, num_envs, num_rbs, num_cues, num_due_pairs, max_links,
+                     pwr_levels_due, pwr_levels_cue, pwr_levels_mbs, cell_radius_m, d2d_radius_m)
+        _check(self._lib.d2d_create(C.byref(cfg), C.byref(self._h)))
+        self.num_envs = num_envs
+        self.num_devices = 1 + num_cues + 2 * num_due_pairs
+        self.max_links = max_links or (num_cues + num_due_pairs)
+        self.num_links = 0
+
+    # -- lifetime
+    def close(self) -> None:
+        if getattr(self, '_h', None):
+            self._lib.d2d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int) -> None:
+        _check(self._lib.d2d_set_stream(self._h, _P(stream_ptr)))
+
+    def synchronize(self) -> None:
+        _check(self._lib.d2d_synchronize(self._h))
+
+    # -- tables
+    def set_device_table(self, eirp_off_db, rx_off_db, noise_dbm, sens_dbm, bw_hz) -> None:
+        cols = [np.ascontiguousarray(c, dtype=np.float64) for c in (eirp_off_db, rx_off_db, noise_dbm, sens_dbm, bw_hz)]
+        _check(self._lib.d2d_set_device_table(self._h, len(cols[0]), *[_dptr(c) for c in cols]))
+
+    def set_path_loss_power_law(self, a_tx_db, a_rx_db, exponent) -> None:
+        cols = [np.ascontiguousarray(c, dtype=np.float64) for c in (a_tx_db, a_rx_db, exponent)]
+        _check(self._lib.d2d_set_path_loss_power_law(self._h, len(cols[0]), *[_dptr(c) for c in cols]))
+
+    def set_path_loss_table(self, pl_db: np.ndarray) -> None:
+        t = np.ascontiguousarray(pl_db, dtype=np.float32)
+        d = self.num_devices
+        if t.shape not in ((d, d), (self.num_envs, d, d)):
+            raise ValueError(f'path-loss table must be [{d},{d}] or [{self.num_envs},{d},{d}], got {t.shape}')
+        _check(self._lib.d2d_set_path_loss_table(self._h, t.ctypes.data_as(_FP), int(t.ndim == 3)))
+
+    def set_links(self, tx_dev, rx_dev, link_type) -> None:
+        a = [np.ascontiguousarray(c, dtype=np.int32) for c in (tx_dev, rx_dev, link_type)]
+        n = len(a[0])
+        _check(self._lib.d2d_set_links(self._h, n, *[c.ctypes.data_as(_IP) for c in a]))
+        self.num_links = n
+
+    def set_reward(self, reward_fn: int, param: float = 0.0) -> None:
+        _check(self._lib.d2d_set_reward(self._h, reward_fn, param))
+
+    def set_obs_mode(self, mode: int) -> None:
+        _check(self._lib.d2d_set_obs_mode(self._h, mode))
+
+    def set_bucketing(self, enabled: bool) -> None:
+        _check(self._lib.d2d_set_bucketing(self._h, int(enabled)))
+
+    def set_tuning(self, key: int, value: int) -> None:
+        _check(self._lib.d2d_set_tuning(self._h, key, value))
+
+    # -- buffers
+    def buffer_shape(self, which: int):
+        b, n, d = self.num_envs, self.num_links, self.num_devices
+        if which in (BUF_POS_X, BUF_POS_Y):
+            return (b, d)
+        if which == BUF_OBS_TABLE:
+            return (b, n, 6)
+        if which == BUF_OBS:
+            return (b, n, 6 * n)
+        if which == BUF_ENV_FLAGS:
+            return (b,)
+        return (b, n)
+
+    def get_buffer(self, which: int):
+        ptr, size = _P(), C.c_size_t()
+        _check(self._lib.d2d_get_buffer(self._h, which, C.byref(ptr), C.byref(size)))
+        return ptr.value, size.value
+
+    def bind_buffer(self, which: int, dev_ptr: int, nbytes: int) -> None:
+        _check(self._lib.d2d_bind_buffer(self._h, which, _P(dev_ptr), nbytes))
+
+    def upload(self, which: int, array: np.ndarray, offset_bytes: int = 0) -> None:
+        a = np.ascontiguousarray(array, dtype=BUFFER_DTYPES.get(which, np.float32))
+        _check(self._lib.d2d_upload(self._h, which, a.ctypes.data_as(_P), a.nbytes, offset_bytes))
+
+    def download(self, which: int, env_begin: int = 0, env_count: Optional[int] = None) -> np.ndarray:
+        shape = self.buffer_shape(which)
+        env_count = self.num_envs - env_begin if env_count is None else env_count
+        out = np.empty((env_count,) + shape[1:], dtype=BUFFER_DTYPES.get(which, np.float32))
+        per_env = out.nbytes // max(env_count, 1)
+        if out.nbytes:
+            _check(self._lib.d2d_download(self._h, which, out.ctypes.data_as(_P), out.nbytes, env_begin * per_env))
+        return out
+
+    def set_positions(self, x: np.ndarray, y: np.ndarray, env_begin: int = 0) -> None:
+        x = np.ascontiguousarray(x, dtype=np.float32); y = np.ascontiguousarray(y, dtype=np.float32)
+        if x.shape != y.shape or x.ndim != 2 or x.shape[1] != self.num_devices:
+            raise ValueError(f'positions must be [envs, {self.num_devices}]')
+        _check(self._lib.d2d_set_positions(self._h, x.ctypes.data_as(_FP), y.ctypes.data_as(_FP), env_begin, x.shape[0]))
+
+    def reset_positions(self, seed: int, episode: int = 0, fixed_mask=None, fixed_xy=None) -> None:
+        m = xy = None
+        if fixed_mask is not None:
+            m = np.ascontiguousarray(fixed_mask, dtype=np.uint8)
+            xy = np.ascontiguousarray(fixed_xy, dtype=np.float32)
+            if m.shape != (self.num_devices,) or xy.shape != (self.num_devices, 2):
+                raise ValueError('fixed_mask [D] / fixed_xy [D,2] expected')
+        _check(self._lib.d2d_reset_positions(
+            self._h, C.c_uint64(seed), C.c_uint64(episode),
+            m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None,
+            xy.ctypes.data_as(_FP) if xy is not None else None))
+
+    def set_env_offset(self, first_env: int) -> None:
+        _check(self._lib.d2d_set_env_offset(self._h, C.c_uint64(first_env)))
+
+    # -- hot path
+    def step(self, actions_ptr: int = 0) -> None:
+        _check(self._lib.d2d_step(self._h, _P(actions_ptr or None)))
+
+    def step_rb_pwr(self, rb_ptr: int = 0, pwr_ptr: int = 0) -> None:
+        _check(self._lib.d2d_step_rb_pwr(self._h, _P(rb_ptr or None), _P(pwr_ptr or None)))
+
+    def status_flags(self) -> int:
+        f = C.c_uint32()
+        _check(self._lib.d2d_status_flags(self._h, C.byref(f)))
+        return f.value
+
+    # -- measurement
+    def profile_enable(self, on: bool) -> None:
+        _check(self._lib.d2d_profile_enable(self._h, int(on)))
+
+    def profile_read(self, kernel: int):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self._lib.d2d_profile_read(self._h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self) -> None:
+        _check(self._lib.d2d_profile_reset(self._h))
+
+    def probe_write_bandwidth(self, nbytes: int, iters: int = 10) -> float:
+        g = C.c_double()
+        _check(self._lib.d2d_probe_write_bandwidth(self._h, nbytes, iters, C.byref(g)))
+        return g.value

@@ -1,0 +1,80 @@
+"""Build libd2d_hip.so for gfx950 with hipcc (in-tree, so the .so travels with the repo snapshot).
+
+    python -m gym_d2d_amd.build [--force] [--verbose]
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / 'csrc'
+LIB_DIR = PKG / 'lib'
+LIB_PATH = LIB_DIR / 'libd2d_hip.so'
+INCLUDE = PKG.parent / 'include'
+ARCH = 'gfx950'
+
+SOURCES = ['d2d_step.hip', 'd2d_obs.hip', 'd2d_reset.hip', 'd2d_capi.hip']
+HEADERS = [CSRC / 'd2d_internal.h', INCLUDE / 'd2d_hip.h']
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-unused-value']
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError('hipcc not found: libd2d_hip.so cannot be built (there is no CPU fallback)')
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for p in [CSRC / s for s in SOURCES if (CSRC / s).exists()] + HEADERS:
+        h.update(p.name.encode()); h.update(p.read_bytes())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    LIB_DIR.mkdir(exist_ok=True)
+    stamp = LIB_DIR / 'libd2d_hip.sha256'
+    digest = _digest()
+    if not force and LIB_PATH.exists() and stamp.exists() and stamp.read_text().strip() == digest:
+        return LIB_PATH
+    hipcc = _hipcc()
+    objs = []
+    obj_dir = LIB_DIR / 'obj'
+    obj_dir.mkdir(exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        src = CSRC / s
+        if not src.exists():
+            continue
+        obj = obj_dir / (src.stem + '.o')
+        cmd = [hipcc, *FLAGS, '-I', str(INCLUDE), '-c', str(src), '-o', str(obj)]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(str(obj))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{out}')
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', str(LIB_PATH), *objs]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stdout}')
+    stamp.write_text(digest)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    path = build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv)
+    print(path)

@@ -1,0 +1,110 @@
+// LinearObsFunction expansion for gfx950 (MI355X): obs[b, i, :] = concat(T[b,i], T[b,0..i-1], T[b,i+1..N-1]).
+//
+// Reference: LinearObsFunction.get_state, envs/obs_fn.py:43-53 (hot loop #2: O(N^2) list.extend + N np.array
+// calls, 86 % of the reference's step time at N = 512).
+//
+// This is the HBM-dominant kernel of the path: 24*N bytes written per agent-step against 24 read.  It is a
+// pure streaming store, so the design is about the store side only:
+//   * T[b] (6N floats) is staged once per workgroup in LDS;
+//   * the output block of an env is contiguous ([N][6N] floats), so a workgroup walks a contiguous slab of
+//     rows with one 16-byte store per lane per iteration - every wave-instruction writes 1 KiB of consecutive
+//     addresses (full 128-B lines, no partial-line read-modify-write);
+//   * row i is T shifted by 6 floats for columns [6, 6(i+1)) and unshifted after that; both boundaries are
+//     even, so every aligned float2 of the output maps to one aligned float2 of T: two conflict-free
+//     ds_read_b64 feed each global_store_dwordx4;
+//   * stores are nontemporal (written once, never re-read by this kernel);
+//   * blockIdx is remapped so the chunks of one env share an XCD (its T stays in that XCD's L2).
+#include "d2d_internal.h"
+
+namespace d2d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// source float index inside T_flat for output column f (even) of row i
+__device__ __forceinline__ unsigned src_col(unsigned f, unsigned i) {
+    const unsigned head = 6u * i;
+    return f < 6u ? head + f : (f < head + 6u ? f - 6u : f);
+}
+
+template <int VEC, bool NT>
+__global__ __launch_bounds__(256) void obs_expand_kernel(const ObsArgs a) {
+    extern __shared__ __align__(16) float t_flat[];          // [6N]
+    const unsigned N = a.N, tid = threadIdx.x;
+    unsigned env, chunk;
+    if (a.xcd_remap) {
+        // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give them the chunks of ONE env
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
+        chunk = rest % a.chunks;
+        env = (rest / a.chunks) * 8u + lane8;
+    } else {
+        env = blockIdx.x / a.chunks;
+        chunk = blockIdx.x % a.chunks;
+    }
+    const unsigned row_floats = 6u * N;
+
+    // stage T[env] (coalesced; 8-byte granules are always aligned because 6N is even)
+    {
+        const f32x2* src = reinterpret_cast<const f32x2*>(a.table + (size_t)env * row_floats);
+        f32x2* dst = reinterpret_cast<f32x2*>(t_flat);
+        for (unsigned k = tid; k < row_floats / 2; k += 256) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    const unsigned r0 = chunk * a.rows_per_wg;
+    const unsigned r1 = min(r0 + (unsigned)a.rows_per_wg, N);
+    const unsigned q_per_row = a.q_per_row;
+    const unsigned total = (r1 - r0) * q_per_row;
+    float* out = a.obs + ((size_t)env * N + r0) * row_floats;   // contiguous slab of rows [r0, r1)
+
+#pragma unroll 4
+    for (unsigned idx = tid; idx < total; idx += 256) {
+        const unsigned lr = (unsigned)(((unsigned long long)idx * a.q_magic) >> 40);   // idx / q_per_row
+        const unsigned q = idx - lr * q_per_row;
+        const unsigned i = r0 + lr;
+        const unsigned f = q * VEC;
+        if (VEC == 4) {
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(t_flat + src_col(f, i));
+            const f32x2 hi = *reinterpret_cast<const f32x2*>(t_flat + src_col(f + 2u, i));
+            const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+            f32x4* p = reinterpret_cast<f32x4*>(out + (size_t)idx * 4);
+            if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+        } else {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(t_flat + src_col(f, i));
+            f32x2* p = reinterpret_cast<f32x2*>(out + (size_t)idx * 2);
+            if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+        }
+    }
+}
+
+hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)a.N * 6 * sizeof(float);
+    dim3 grid((unsigned)a.B * (unsigned)a.chunks), block(256);
+    if (a.vec == 4) {
+        if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<4, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((obs_expand_kernel<4, false>), grid, block, lds, stream, a);
+    } else {
+        if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<2, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((obs_expand_kernel<2, false>), grid, block, lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
+// Streaming-store probe: the on-box ceiling for a write-only 16-B/lane stream (d2d_probe_write_bandwidth).
+__global__ __launch_bounds__(256) void fill_kernel(f32x4* dst, size_t n, float value) {
+    const f32x4 v = {value, value, value, value};
+    const size_t stride = (size_t)gridDim.x * 256;
+#pragma unroll 4
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) __builtin_nontemporal_store(v, dst + k);
+}
+
+hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream) {
+    size_t blocks = (n_float4 + 255) / 256;
+    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<f32x4*>(dst),
+                       n_float4, value);
+    return hipGetLastError();
+}
+
+}  // namespace d2d

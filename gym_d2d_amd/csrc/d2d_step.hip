@@ -1,0 +1,319 @@
+// Fused per-step kernel for gfx950 (MI355X): action decode -> received signal -> same-RB interference
+// reduction -> SINR / SNR / Shannon rate / capacity -> reward -> compact observation table.
+//
+// Reference path being replaced (file:line under /root/reference/src/gym_d2d):
+//   D2DEnv._decode_action            envs/d2d_env.py:93-101
+//   Simulator._calculate_sinrs       simulator.py:89-108      (hot loop #1)
+//   Simulator._calculate_snrs        simulator.py:110-116
+//   Simulator._calculate_rates       simulator.py:118-127
+//   Simulator._calculate_network_capacity  simulator.py:144-154
+//   Actions.get_actions_by_rb        actions.py:27-31
+//   {SystemCapacity,Shannon,CueSinrShannon}RewardFunction   envs/reward_fn.py:22-78
+//   LinearObsFunction._agent_obs     envs/obs_fn.py:55-61
+//
+// Design (one workgroup = one environment; environments are independent):
+//   * every link's transmitter tuple (tx_x, tx_y, effective tx power in mW, rb) is staged once in LDS as a
+//     float4, so the interference loop is one ds_read_b128 per candidate interferer;
+//   * same-RB interferers are found through per-RB membership bitmasks in LDS (R x ceil(N/64) u64 words,
+//     built with ds_or_b64 - order independent), walked in ascending link order with ctz; a masked
+//     all-pairs sweep is the fallback (rb outside [0,R), or mask table too large) and produces bit-identical
+//     sums because both walk interferers in ascending index order through the same fmaf;
+//   * all arithmetic is in the LINEAR domain (mW): sinr = S / (I + N) with one 10*log10 at the end; the
+//     literal dB-domain transcription cannot hold 1e-5 relative in fp32 (hard parts);
+//   * reductions (capacity sum) are xor-butterfly wave reductions + a fixed-order cross-wave sum:
+//     run-to-run deterministic.
+#include "d2d_internal.h"
+
+namespace d2d {
+
+typedef unsigned long long u64;
+
+#define FLAG_ZERO_DISTANCE 1
+#define FLAG_RB_OOR 2
+#define FLAG_NON_FINITE 4
+
+#define LINK_UPLINK 1
+#define LINK_DOWNLINK 2
+#define LINK_SIDELINK 3
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// (d^2)^(-e/2) for arbitrary exponent e, to ~3e-7 relative.  log2 of the mantissa and the integer exponent
+// are handled separately so the error does not scale with |log2(d^2)| (a plain exp2(h*log2(x)) loses ~2e-6).
+__device__ __forceinline__ float pow_neg_half(float d2, float e) {
+    const float m = __builtin_amdgcn_frexp_mantf(d2);       // [0.5, 1)
+    const float fe = (float)__builtin_amdgcn_frexp_expf(d2);
+    const float l = __builtin_amdgcn_logf(m);               // v_log_f32 = log2, in [-1, 0)
+    const float h = -0.5f * e;
+    const float p = h * fe;
+    const float perr = fmaf(h, fe, -p);                     // exact residual of the product
+    const float ip = rintf(p);
+    const float fr = (p - ip) + fmaf(h, l, perr);
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(fr), (int)ip);
+}
+
+template <int MODE>
+__device__ __forceinline__ float pair_gain(float d2, float e) {
+    if (MODE == PL_INV_SQUARE) return __builtin_amdgcn_rcpf(d2);
+    return pow_neg_half(d2, e);
+}
+
+// LDS carve-up.  44 bytes per link + masks.
+struct Smem {
+    float4* link;   // [N] tx_x, tx_y, effective tx power (mW, incl. tx side of the PL constant), rb bits
+    float2* rx;     // [N] rx_x, rx_y
+    float* cap;     // [N] capacity_mbps
+    float* sinr;    // [N] sinr_db
+    float* sh;      // [N] log2(1 + sinr_lin)
+    float* expo;    // [N] path-loss exponent of the tx
+    int* aux;       // [N] tx_dev | link_type << 24
+    float* red;     // [32]
+    int* flags;     // [4]  0: env flags  1: reward violated
+    u64* mask;      // [R*W] per-RB membership, then [W] sidelink membership
+};
+
+__device__ __forceinline__ Smem carve(unsigned char* base, int N) {
+    Smem s;
+    s.link = reinterpret_cast<float4*>(base);
+    s.rx = reinterpret_cast<float2*>(s.link + N);
+    s.cap = reinterpret_cast<float*>(s.rx + N);
+    s.sinr = s.cap + N;
+    s.sh = s.sinr + N;
+    s.expo = s.sh + N;
+    s.aux = reinterpret_cast<int*>(s.expo + N);
+    s.red = reinterpret_cast<float*>(s.aux + N);
+    s.flags = reinterpret_cast<int*>(s.red + 32);
+    s.mask = reinterpret_cast<u64*>(s.flags + 4);
+    return s;
+}
+
+size_t step_lds_bytes(int N, int R, int mask_words) {
+    size_t bytes = (size_t)N * 44 + 32 * 4 + 4 * 4;
+    bytes = (bytes + 7) & ~(size_t)7;
+    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words) * 8;
+    return bytes;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int N = a.N, R = a.R, D = a.D, W = a.mask_words;
+    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const size_t row = (size_t)b * N;
+    Smem s = carve(smem_raw, N);
+    // carve() aligns the mask region to 8 bytes the same way step_lds_bytes does
+    s.mask = reinterpret_cast<u64*>((reinterpret_cast<uintptr_t>(s.flags + 4) + 7) & ~(uintptr_t)7);
+
+    // ---- pass 0: clear masks and flags
+    const bool want_masks = W > 0;
+    if (want_masks)
+        for (int k = tid; k < R * W + W; k += T) s.mask[k] = 0ull;
+    if (tid < 4) s.flags[tid] = 0;
+    __syncthreads();
+
+    // ---- pass 1: decode + stage the transmitter side of every link
+    const float* px = a.pos_x + (size_t)b * D;
+    const float* py = a.pos_y + (size_t)b * D;
+    for (int i = tid; i < N; i += T) {
+        const int type = a.link_type[i], txd = a.link_tx[i], rxd = a.link_rx[i];
+        int rb, p;
+        if (a.action_mode == 0) {
+            // d2d_env.py:94-96 with Python floor semantics; NB due_min_tx_power_dBm is not added back
+            const int act = a.actions[row + i];
+            const int P = type == LINK_SIDELINK ? a.p_due : (type == LINK_UPLINK ? a.p_cue : a.p_mbs);
+            int q = act / P, r = act - q * P;
+            if (r < 0) { r += P; q -= 1; }
+            rb = q; p = r;
+        } else {
+            rb = a.rb_in[row + i]; p = a.pwr_in[row + i];
+        }
+        const float p10 = (unsigned)p < 128u ? a.pow10_tab[p] : exp10f(0.1f * (float)p);
+        s.link[i] = make_float4(px[txd], py[txd], p10 * a.dev_tx_lin[txd], __int_as_float(rb));
+        s.rx[i] = make_float2(px[rxd], py[rxd]);
+        s.aux[i] = txd | (type << 24);
+        if (MODE == PL_POWER) s.expo[i] = a.dev_exp[txd];
+        if (a.rb_out) { a.rb_out[row + i] = rb; a.pwr_out[row + i] = p; }
+        if (want_masks) {
+            const u64 bit = 1ull << (i & 63);
+            if ((unsigned)rb < (unsigned)R) atomicOr(&s.mask[(size_t)rb * W + (i >> 6)], bit);
+            else atomicOr(&s.flags[0], FLAG_RB_OOR);
+            if (type == LINK_SIDELINK) atomicOr(&s.mask[(size_t)R * W + (i >> 6)], bit);
+        }
+    }
+    __syncthreads();
+    const bool use_masks = want_masks && !(s.flags[0] & FLAG_RB_OOR);
+    const float* gtab = MODE == PL_TABLE ? a.gain_table + (size_t)b * a.table_env_stride : nullptr;
+
+    // ---- pass 2: interference reduction + SINR/SNR/rate/capacity + obs table
+    float cap_part = 0.0f;
+    int my_flags = 0;
+    for (int i = tid; i < N; i += T) {
+        const float4 me = s.link[i];
+        const float2 rx = s.rx[i];
+        const int rb = __float_as_int(me.w);
+        const int txd = s.aux[i] & 0xFFFFFF;
+        const int rxd = a.link_rx[i];
+        float acc = 0.0f;
+        bool zero = false;
+
+        if (use_masks) {
+            const u64* m = s.mask + (size_t)rb * W;
+            for (int w = 0; w < W; ++w) {
+                u64 word = m[w];
+                if (w == (i >> 6)) word &= ~(1ull << (i & 63));          // .difference({action}), simulator.py:95
+                while (word) {
+                    const int j = (w << 6) + __builtin_ctzll(word);
+                    word &= word - 1;
+                    const float4 o = s.link[j];
+                    const float dx = o.x - rx.x, dy = o.y - rx.y;
+                    const float d2 = fmaf(dx, dx, dy * dy);
+                    float g;
+                    if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
+                    else { g = pair_gain<MODE>(d2, MODE == PL_POWER ? s.expo[j] : 2.0f); zero |= d2 == 0.0f; }
+                    acc = fmaf(o.z, g, acc);                             // simulator.py:97-101, linear mW
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int j = 0; j < N; ++j) {
+                const float4 o = s.link[j];                              // same address in every lane: LDS broadcast
+                const bool same = (__float_as_int(o.w) == rb) & (j != i);
+                const float dx = o.x - rx.x, dy = o.y - rx.y;
+                const float d2 = fmaf(dx, dx, dy * dy);
+                float g;
+                if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
+                else { g = pair_gain<MODE>(d2, MODE == PL_POWER ? s.expo[j] : 2.0f); zero |= same & (d2 == 0.0f); }
+                acc = same ? fmaf(o.z, g, acc) : acc;
+            }
+        }
+
+        // own link: simulator.py:93
+        const float dx = me.x - rx.x, dy = me.y - rx.y;
+        const float d2 = fmaf(dx, dx, dy * dy);
+        float g;
+        if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
+        else { g = pair_gain<MODE>(d2, MODE == PL_POWER ? s.expo[i] : 2.0f); zero |= d2 == 0.0f; }
+        const float rx_pl = a.dev_rx_pl[rxd];
+        const float sig = me.z * g * rx_pl * a.dev_rx_lin[rxd];          // mW at the receiver, with rx gains
+        const float ix = acc * rx_pl;                                    // interferers: no rx gains (simulator.py:100)
+        const float noise = a.dev_noise_mw[rxd];
+        const float sinr_lin = sig / (ix + noise);
+        const float sinr_db = 10.0f * log10f(sinr_lin);                  // simulator.py:106-107
+        const float snr_db = 10.0f * log10f(sig / noise);                // simulator.py:115
+        const float sh = log1pf(sinr_lin) * 1.44269504088896340736f;     // log2(1 + sinr)
+        const bool ok = sinr_db > a.dev_sens_db[rxd];                    // simulator.py:123,149
+        const float rate = ok ? sh : 0.0f;
+        const float cap = ok ? a.dev_bw_mhz[txd] * sh : 0.0f;            // simulator.py:150-151
+
+        a.sinr_db[row + i] = sinr_db;
+        a.snr_db[row + i] = snr_db;
+        a.rate[row + i] = rate;
+        a.cap[row + i] = cap;
+        if (a.write_table) {                                             // obs_fn.py:57-60
+            float2* t = reinterpret_cast<float2*>(a.table + (row + i) * 6);
+            t[0] = make_float2(me.x, me.y);
+            t[1] = rx;
+            t[2] = make_float2(sinr_db, snr_db);
+        }
+        s.cap[i] = cap; s.sinr[i] = sinr_db; s.sh[i] = sh;
+        cap_part += cap;
+        if (zero) my_flags |= FLAG_ZERO_DISTANCE;
+        if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
+    }
+    if (my_flags) atomicOr(&s.flags[0], my_flags);
+
+    // ---- pass 3: reward
+    if (a.reward_fn == 1) {
+        // SystemCapacityRewardFunction, reward_fn.py:27-44
+        const float wsum = wave_sum(cap_part);
+        if ((tid & 63) == 0) s.red[tid >> 6] = wsum;
+        __syncthreads();                                                 // also publishes s.cap
+        for (int j = tid; j < N; j += T) {
+            const int tj = s.aux[j] >> 24;
+            if (tj == LINK_SIDELINK || !(s.cap[j] <= a.reward_param)) continue;
+            const int rbj = __float_as_int(s.link[j].w);
+            bool hit = false;
+            if (use_masks) {
+                for (int w = 0; w < W; ++w) hit |= (s.mask[(size_t)rbj * W + w] & s.mask[(size_t)R * W + w]) != 0ull;
+            } else {
+                for (int i = 0; i < N; ++i)
+                    hit |= (i != j) & ((s.aux[i] >> 24) == LINK_SIDELINK) & (__float_as_int(s.link[i].w) == rbj);
+            }
+            if (hit) atomicOr(&s.flags[1], 1);
+        }
+        __syncthreads();
+        float total = 0.0f;
+        const int nw = (T + 63) >> 6;
+        for (int w = 0; w < nw; ++w) total += s.red[w];
+        const float r = s.flags[1] ? -1.0f : total / (float)N;
+        for (int i = tid; i < N; i += T) a.reward[row + i] = r;
+    } else if (a.reward_fn == 2) {
+        // ShannonRewardFunction, reward_fn.py:52-57
+        for (int i = tid; i < N; i += T) a.reward[row + i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
+        __syncthreads();
+    } else if (a.reward_fn == 3) {
+        // CueSinrShannonRewardFunction, reward_fn.py:65-78
+        __syncthreads();
+        for (int i = tid; i < N; i += T) {
+            const int rbi = __float_as_int(s.link[i].w);
+            bool bad = false;
+            if (use_masks) {
+                for (int w = 0; w < W; ++w) {
+                    u64 word = s.mask[(size_t)rbi * W + w] & ~s.mask[(size_t)R * W + w];   // non-sidelink members
+                    if (w == (i >> 6)) word &= ~(1ull << (i & 63));
+                    while (word) {
+                        const int j = (w << 6) + __builtin_ctzll(word);
+                        word &= word - 1;
+                        bad |= s.sinr[j] < a.reward_param;
+                    }
+                }
+            } else {
+                for (int j = 0; j < N; ++j)
+                    bad |= (j != i) & ((s.aux[j] >> 24) != LINK_SIDELINK) & (__float_as_int(s.link[j].w) == rbi) &
+                           (s.sinr[j] < a.reward_param);
+            }
+            a.reward[row + i] = bad ? -1.0f : s.sh[i];
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        const int f = s.flags[0];
+        a.env_flags[b] = f;
+        if (f) atomicOr(a.status, (unsigned)f);
+    }
+}
+
+hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream) {
+    int threads = ((a.N + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    if (threads < 64) threads = 64;
+    const size_t lds = step_lds_bytes(a.N, a.R, a.mask_words);
+    dim3 grid(a.B), block(threads);
+    hipError_t err = hipSuccess;
+#define D2D_LAUNCH(M)                                                                                    \
+    do {                                                                                                 \
+        if (lds > 48 * 1024)                                                                             \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        if (err == hipSuccess) {                                                                         \
+            hipLaunchKernelGGL(step_kernel<M>, grid, block, lds, stream, a);                             \
+            err = hipGetLastError();                                                                     \
+        }                                                                                                \
+    } while (0)
+    switch (mode) {
+        case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;
+        case PL_POWER: D2D_LAUNCH(PL_POWER); break;
+        case PL_TABLE: D2D_LAUNCH(PL_TABLE); break;
+    }
+#undef D2D_LAUNCH
+    return err;
+}
+
+}  // namespace d2d

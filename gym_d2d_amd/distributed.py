@@ -1,0 +1,87 @@
+"""Multi-GPU: one process per GPU, the env axis sharded contiguously, no exchange inside the step.
+
+Environments share nothing (interference, reward and observation all reduce within one env - SURVEY.md 8(e)), so the
+only communication is what a single learner wants to see at the end of a step: one all-gather of the per-env rewards
+(B_local floats) and of the COMPACT observation table T[B_local, N, 6].  The expanded LinearObs tensor [B, N, 6N]
+is never sent: a consumer re-expands T locally (25.8 GB/GPU over one ~153 GB/s xGMI link per ring hop would take
+seconds per step).
+
+The gather runs on a side stream from a staging copy of T, so it overlaps the obs-expansion kernel and the next
+step; only the 50 MB device-to-device staging copy is ordered against the next step's writes.
+Backend "nccl" is RCCL on ROCm; "gloo" works for CPU tensors (used by the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_envs: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [begin, end) of env indices owned by `rank`; remainders go to the low ranks."""
+    if not 0 <= rank < world_size:
+        raise ValueError('rank out of range')
+    base, extra = divmod(global_envs, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+class StepGatherer:
+    """All-gather of (rewards[B_local], table[B_local, N, 6]) across ranks with equal shard sizes."""
+
+    def __init__(self, b_local: int, n_links: int, device: torch.device, group=None) -> None:
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = device
+        self.cuda = device.type == 'cuda'
+        f32 = torch.float32
+        self.stage_reward = torch.empty(b_local, dtype=f32, device=device)
+        self.stage_table = torch.empty((b_local, n_links, 6), dtype=f32, device=device)
+        self.all_reward = torch.empty(self.world * b_local, dtype=f32, device=device)
+        self.all_table = torch.empty((self.world * b_local, n_links, 6), dtype=f32, device=device)
+        if self.cuda:
+            self.comm_stream = torch.cuda.Stream(device=device)
+            self.staged = torch.cuda.Event()
+            self.done = torch.cuda.Event()
+        self._pending = False
+
+    def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor) -> None:
+        """Call right after the step was enqueued on the current stream.  reward_per_agent [B_local, N] (column 0
+        is the env's scalar for SystemCapacity), table [B_local, N, 6]."""
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            self.comm_stream.wait_stream(cur)                   # results of this step are ready
+            with torch.cuda.stream(self.comm_stream):
+                self.stage_reward.copy_(reward_per_agent[:, 0])
+                self.stage_table.copy_(table)
+                self.staged.record(self.comm_stream)
+                dist.all_gather_into_tensor(self.all_reward, self.stage_reward, group=self.group)
+                dist.all_gather_into_tensor(self.all_table, self.stage_table, group=self.group)
+                self.done.record(self.comm_stream)
+            cur.wait_event(self.staged)                         # next step may overwrite table/reward now
+        else:
+            self.stage_reward.copy_(reward_per_agent[:, 0])
+            self.stage_table.copy_(table)
+            dist.all_gather_into_tensor(self.all_reward, self.stage_reward, group=self.group)
+            dist.all_gather_into_tensor(self.all_table, self.stage_table, group=self.group)
+        self._pending = True
+
+    def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(rewards [B_global], table [B_global, N, 6]) of the last launched gather, rank-major = env order."""
+        if self.cuda and self._pending:
+            torch.cuda.current_stream(self.device).wait_event(self.done)
+        self._pending = False
+        return self.all_reward, self.all_table
+
+
+def expand_table(table: torch.Tensor) -> torch.Tensor:
+    """Consumer-side LinearObs expansion of a gathered table [B, N, 6] -> [B, N, 6N] with torch ops (what a learner on
+    another GPU does instead of receiving the expanded tensor).  obs[b,i] = (T[i], T[0..i-1], T[i+1..])."""
+    b, n, w = table.shape
+    idx = torch.arange(n, device=table.device)
+    k = torch.arange(n, device=table.device)
+    # source link for slot k of agent i: i for k = 0; k-1 for 1 <= k <= i; k for k > i
+    src = torch.where(k[None, :] == 0, idx[:, None], torch.where(k[None, :] <= idx[:, None], k[None, :] - 1, k[None, :]))
+    return table[:, src, :].reshape(b, n, n * w)

@@ -1,0 +1,161 @@
+"""PathLoss plugins (mirrors gym_d2d/path_loss.py) and their lowering to the HIP kernels.
+
+Plugin contract (unchanged from the reference): a PathLoss class is passed in env_config['path_loss_model'],
+is constructed with one positional argument (carrier_freq_GHz) and is callable as model(tx, rx) -> dB.
+
+Lowering: every built-in model is a power law in distance,
+    PL_dB(tx, rx) = a_tx[tx] + a_rx[rx] + 10 * n[tx] * log10(d_m),
+so `power_law_columns(devices)` returns the three per-device float64 columns for d2d_set_path_loss_power_law()
+and the kernel evaluates gain = 10^(-(a_tx+a_rx)/10) * d^-n in the linear domain (one v_rcp per pair when n == 2).
+A user subclass that only defines __call__ is evaluated on the host once per episode into a [D,D] table
+(`table_db`, d2d_set_path_loss_table) - legal because positions are static between resets (simulator.py:61-75).
+"""
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+from enum import Enum
+from random import gauss
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .device import Device
+
+SPEED_OF_LIGHT = 299792458  # m/s
+
+
+class PathLoss(ABC):
+    def __init__(self, carrier_freq_GHz: float) -> None:
+        self.carrier_freq_GHz = float(carrier_freq_GHz)
+
+    @abstractmethod
+    def __call__(self, tx: Device, rx: Device) -> float:
+        """Path loss in dB from `tx` to `rx`."""
+
+    # ---- lowering hooks -------------------------------------------------------------------------------
+    def power_law_columns(self, devices: Sequence[Device]) -> Optional[Dict[str, np.ndarray]]:
+        """Per-device columns {'a_tx_db', 'a_rx_db', 'exponent'} if the model is a power law in distance,
+        else None (the table route is used)."""
+        return None
+
+    def table_db(self, devices: Sequence[Device]) -> np.ndarray:
+        """Host evaluation of every ordered device pair: out[tx_index, rx_index] in dB.  A pair the model cannot
+        evaluate (zero distance -> ValueError in math.log10) is stored as NaN; the env raises if such a pair is
+        ever used, which is when the reference would have raised."""
+        devs = list(devices)
+        out = np.full((len(devs), len(devs)), np.nan, dtype=np.float64)
+        for i, tx in enumerate(devs):
+            for j, rx in enumerate(devs):
+                if i == j:
+                    continue
+                try:
+                    out[i, j] = self(tx, rx)
+                except (ValueError, ZeroDivisionError):
+                    pass
+        return out
+
+
+def pl_constant_dB(carrier_freq_GHz: float, ple: float) -> float:
+    """Distance-independent part of the log-distance model: 10 n log10(f_Hz) + 10 n log10(4 pi / c)."""
+    scale = 10 * ple
+    return scale * math.log10(carrier_freq_GHz * 1e9) + scale * math.log10((4 * math.pi) / SPEED_OF_LIGHT)
+
+
+class LogDistancePathLoss(PathLoss):
+    """PL = 10 n log10(d) + 10 n log10(f) + 10 n log10(4 pi / c)   (path_loss.py:42-66)."""
+
+    def __init__(self, carrier_freq_GHz: float, ple=2.0) -> None:
+        super().__init__(carrier_freq_GHz)
+        self.ple = float(ple)   # 2.0 = free space, ~3.5 = cluttered
+        self.pl_constant_dB = pl_constant_dB(carrier_freq_GHz, ple)
+
+    def _log_distance_path_loss(self, dist_m: float) -> float:
+        return 10 * self.ple * math.log10(dist_m) + self.pl_constant_dB
+
+    def __call__(self, tx: Device, rx: Device) -> float:
+        return self._log_distance_path_loss(tx.position.distance(rx.position))
+
+    def power_law_columns(self, devices):
+        if type(self).__call__ is not LogDistancePathLoss.__call__:
+            return None     # a subclass changed the formula: evaluate it on the host instead
+        n = len(devices)
+        return {'a_tx_db': np.full(n, self.pl_constant_dB), 'a_rx_db': np.zeros(n), 'exponent': np.full(n, self.ple)}
+
+
+class FreeSpacePathLoss(LogDistancePathLoss):
+    """Free-space (Friis) loss = log-distance with exponent 2 (the reference's own comment, path_loss.py:45).
+    Not present in the reference snapshot; named by BASELINE.json config 4."""
+
+    def __init__(self, carrier_freq_GHz: float) -> None:
+        super().__init__(carrier_freq_GHz, ple=2.0)
+
+
+class ShadowingPathLoss(LogDistancePathLoss):
+    """Log-distance with log-normal shadowing beyond a close-in distance (path_loss.py:69-81).  A fresh Gaussian
+    is drawn on every call, so this model cannot be frozen into a table."""
+
+    def __init__(self, carrier_freq_GHz: float, ple=2.0, d0_m=100.0, chi_dB=2.7) -> None:
+        super().__init__(carrier_freq_GHz, ple)
+        self.d0_m = float(d0_m)
+        self.chi_dB = float(chi_dB)
+
+    def __call__(self, tx: Device, rx: Device) -> float:
+        d = tx.position.distance(rx.position)
+        if d <= self.d0_m:
+            return self._log_distance_path_loss(d)
+        anchor = self._log_distance_path_loss(self.d0_m)
+        return anchor + 10 * self.ple * math.log10(d / self.d0_m) + gauss(0, self.chi_dB)
+
+    def power_law_columns(self, devices):
+        raise NotImplementedError('ShadowingPathLoss draws a new Gaussian per call; its device-side RNG route is '
+                                  'not built yet (SURVEY.md 8(f) rank 3)')
+
+
+class AreaType(Enum):
+    RURAL = 0
+    SUBURBAN = 1
+    URBAN = 2
+
+
+class CostHataPathLoss(PathLoss):
+    """COST-231 Hata (path_loss.py:90-123):
+       L = 46.3 + 33.9 log10(f_MHz) - 13.82 log10(h_tx) - a(h_rx) + (44.9 - 6.55 log10(h_tx)) log10(d_km) + C."""
+
+    def __init__(self, carrier_freq_GHz: float, area_type=AreaType.SUBURBAN) -> None:
+        super().__init__(carrier_freq_GHz)
+        self.area_type: AreaType = area_type
+
+    def _ms_h_correction(self, f: float, h_rx: float) -> float:
+        """Mobile-station antenna height correction a(h_rx) for carrier f in MHz."""
+        if self.area_type != AreaType.URBAN:
+            return (1.1 * math.log10(f) - 0.7) * h_rx - (1.56 * math.log10(f) - 0.8)
+        if f >= 200:
+            return 8.29 * math.log10(1.54 * h_rx) ** 2 - 1.1
+        return 3.2 * math.log10(11.75 * h_rx) ** 2 - 4.97
+
+    def _slope(self, h_tx: float) -> float:
+        return 44.9 - 6.55 * math.log10(h_tx)
+
+    def __call__(self, tx: Device, rx: Device) -> float:
+        f = self.carrier_freq_GHz * 1000
+        d_km = tx.position.distance(rx.position) / 1000
+        h_tx, h_rx = tx.antenna_height_m, rx.antenna_height_m
+        metro = 3 if self.area_type == AreaType.URBAN else 0
+        return (46.3 + 33.9 * math.log10(f) - 13.82 * math.log10(h_tx) - self._ms_h_correction(f, h_rx)
+                + self._slope(h_tx) * math.log10(d_km) + metro)
+
+    def power_law_columns(self, devices):
+        if type(self).__call__ is not CostHataPathLoss.__call__:
+            return None
+        f = self.carrier_freq_GHz * 1000
+        metro = 3 if self.area_type == AreaType.URBAN else 0
+        a_tx, a_rx, expo = [], [], []
+        for dev in devices:
+            h = dev.antenna_height_m
+            slope = self._slope(h)
+            # log10(d_km) = log10(d_m) - 3: fold the -3*slope into the tx constant
+            a_tx.append(46.3 + 33.9 * math.log10(f) - 13.82 * math.log10(h) + metro - 3.0 * slope)
+            a_rx.append(-self._ms_h_correction(f, h))
+            expo.append(slope / 10.0)
+        return {'a_tx_db': np.array(a_tx), 'a_rx_db': np.array(a_rx), 'exponent': np.array(expo)}

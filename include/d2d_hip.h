@@ -1,0 +1,197 @@
+/*
+ * d2d_hip.h - C ABI of libd2d_hip.so: the MI355X (gfx950) implementation of GymD2D's per-step
+ * SINR / interference path, batched over B independent environments.
+ *
+ * This is the drop-in boundary.  The reference (davidcotton/gym-d2d v0.0.3, pure Python) has no
+ * FFI of its own; each entry point below names the reference interface it replaces (file:line under
+ * /root/reference/src/gym_d2d) and INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns a d2d_status (0 = ok); d2d_last_error() gives text.
+ *   - "host" pointers are read/written synchronously before the call returns.
+ *   - "device" pointers are HIP device memory on the handle's GPU; work on them is enqueued on the
+ *     handle's stream and is asynchronous unless stated.
+ *   - layout: row-major, env axis outermost.  B envs, D devices/env (0 = base station, 1..C = CUEs,
+ *     then DUE tx/rx interleaved - devices.py:20-25), N links/step.
+ *   - a handle is not thread-safe (the reference is single-threaded too).
+ */
+#ifndef D2D_HIP_H
+#define D2D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2D_ABI_VERSION 1
+#define D2D_MAX_LINKS 2048      /* links per env the step kernel's LDS staging is sized for */
+
+typedef struct d2d_handle d2d_handle;
+
+typedef enum d2d_status {
+    D2D_OK = 0,
+    D2D_ERR_INVALID = 1,        /* bad argument / inconsistent sizes                        */
+    D2D_ERR_HIP = 2,            /* a HIP runtime call failed (text in d2d_last_error)       */
+    D2D_ERR_STATE = 3,          /* call order: tables / links / positions not set yet       */
+    D2D_ERR_UNSUPPORTED = 4
+} d2d_status;
+
+/* link_type.py:4-7 */
+typedef enum d2d_link_type { D2D_UPLINK = 1, D2D_DOWNLINK = 2, D2D_SIDELINK = 3 } d2d_link_type;
+
+/* reward_fn.py:22-78 */
+typedef enum d2d_reward_fn {
+    D2D_REWARD_NONE = 0,
+    D2D_REWARD_SYSTEM_CAPACITY = 1,   /* param = min_capacity_mbps   (reward_fn.py:23-44) */
+    D2D_REWARD_SHANNON = 2,           /* param = min_sinr            (reward_fn.py:48-57) */
+    D2D_REWARD_CUE_SINR_SHANNON = 3   /* param = sinr_threshold_dB   (reward_fn.py:61-78) */
+} d2d_reward_fn;
+
+/* obs_fn.py:43-61 */
+typedef enum d2d_obs_mode {
+    D2D_OBS_NONE = 0,
+    D2D_OBS_TABLE = 1,   /* compact base table T[B,N,6] = (tx_x,tx_y,rx_x,rx_y,sinr_db,snr_db) only */
+    D2D_OBS_LINEAR = 2   /* + LinearObsFunction expansion obs[B,N,6N] (reference semantics)         */
+} d2d_obs_mode;
+
+/* buffers addressable through d2d_get_buffer / d2d_bind_buffer / d2d_upload / d2d_download */
+typedef enum d2d_buffer {
+    D2D_BUF_POS_X = 0,      /* f32 [B,D]   device x positions (simulator.py:61-75)                  */
+    D2D_BUF_POS_Y = 1,      /* f32 [B,D]                                                            */
+    D2D_BUF_ACTIONS = 2,    /* i32 [B,N]   raw discrete actions (d2d_env.py:93-96)                  */
+    D2D_BUF_RB = 3,         /* i32 [B,N]   decoded resource block                                   */
+    D2D_BUF_PWR = 4,        /* i32 [B,N]   decoded tx power, dBm                                    */
+    D2D_BUF_SINR_DB = 5,    /* f32 [B,N]   state['sinrs_db']       (simulator.py:89-108)            */
+    D2D_BUF_SNR_DB = 6,     /* f32 [B,N]   state['snrs_db']        (simulator.py:110-116)           */
+    D2D_BUF_RATE_BPS = 7,   /* f32 [B,N]   state['rate_bps']       (simulator.py:118-127)           */
+    D2D_BUF_CAPACITY = 8,   /* f32 [B,N]   state['capacity_mbps']  (simulator.py:144-154)           */
+    D2D_BUF_REWARD = 9,     /* f32 [B,N]   per-agent reward        (reward_fn.py)                   */
+    D2D_BUF_OBS_TABLE = 10, /* f32 [B,N,6]                          (obs_fn.py:55-61)               */
+    D2D_BUF_OBS = 11,       /* f32 [B,N,6N]                         (obs_fn.py:43-53)               */
+    D2D_BUF_ENV_FLAGS = 12, /* i32 [B]     D2D_FLAG_* bits raised by the last step                  */
+    D2D_BUF_COUNT = 13
+} d2d_buffer;
+
+#define D2D_FLAG_ZERO_DISTANCE 1u /* an interacting tx/rx pair at distance 0: the reference raises
+                                     ValueError('math domain error') here (path_loss.py:66)          */
+#define D2D_FLAG_RB_OUT_OF_RANGE 2u /* rb outside [0,num_rbs): accepted like the reference does
+                                     (d2d_env.py:94-96); the env took the all-pairs code path       */
+#define D2D_FLAG_NON_FINITE 4u    /* a non-finite SINR was produced                                  */
+
+/* EnvConfig fields the device side needs (env_config.py:12-27) + batch geometry (new). */
+typedef struct d2d_config {
+    int32_t abi_version;      /* D2D_ABI_VERSION                                                    */
+    int32_t device_ordinal;   /* HIP device to create the handle on                                 */
+    int32_t num_envs;         /* B                                                                  */
+    int32_t num_rbs;          /* env_config.py:12                                                   */
+    int32_t num_cues;         /* env_config.py:13                                                   */
+    int32_t num_due_pairs;    /* env_config.py:14                                                   */
+    int32_t max_links;        /* capacity of the per-link buffers; 0 -> num_cues + num_due_pairs    */
+    int32_t pwr_levels_due;   /* due_max - due_min + 1   (d2d_env.py:32)                            */
+    int32_t pwr_levels_cue;   /* cue_max + 1             (d2d_env.py:33)                            */
+    int32_t pwr_levels_mbs;   /* mbs_max + 1             (d2d_env.py:34)                            */
+    float cell_radius_m;      /* env_config.py:15                                                   */
+    float d2d_radius_m;       /* env_config.py:16                                                   */
+} d2d_config;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* Simulator.__init__ (simulator.py:54-59): allocate the SoA state for B envs on one GPU.           */
+int d2d_create(const d2d_config* cfg, d2d_handle** out);
+int d2d_destroy(d2d_handle* h);
+const char* d2d_last_error(void);
+int d2d_abi_version(void);
+
+/* Run on a caller-supplied hipStream_t (e.g. torch's current stream); NULL -> the handle's own.    */
+int d2d_set_stream(d2d_handle* h, void* hip_stream);
+int d2d_synchronize(d2d_handle* h);
+
+/* ---- static tables (host pointers, copied) --------------------------------------------------- */
+/* Per-device link-budget columns, n_dev = 1 + C + 2P entries each, replacing Device.eirp_dBm /
+ * rx_signal_level_dBm / thermal_noise_dBm / rx_sensitivity_dBm / rb_bandwidth_kHz
+ * (device.py:51-80,85-95,130-173):
+ *   eirp_off_db[d] = eirp_dBm(p) - p ; rx_off_db[d] = rx_signal_level_dBm(e, pl) - (e - pl) ;
+ *   noise_dbm[d] = thermal_noise_dBm ; sens_dbm[d] = rx_sensitivity_dBm ; bw_hz[d] = RB bandwidth. */
+int d2d_set_device_table(d2d_handle* h, int32_t n_dev, const double* eirp_off_db, const double* rx_off_db,
+                         const double* noise_dbm, const double* sens_dbm, const double* bw_hz);
+
+/* PathLoss plugin, native route (path_loss.py:42-66,90-123).  Any model of the form
+ *   PL_dB(tx, rx) = a_tx_db[tx] + a_rx_db[rx] + 10 * exponent[tx] * log10(distance_m)
+ * LogDistance/FreeSpace: a_tx = pl_constant_dB, a_rx = 0, exponent = ple.  COST-Hata: see
+ * gym_d2d_amd/path_loss.py.  Arrays have n_dev entries.                                            */
+int d2d_set_path_loss_power_law(d2d_handle* h, int32_t n_dev, const double* a_tx_db, const double* a_rx_db,
+                                const double* exponent);
+
+/* PathLoss plugin, table route for arbitrary Python subclasses (path_loss.py:12-25;
+ * examples/custom_path_loss.py:8-16): pl_db[(e,) tx_dev, rx_dev] evaluated on the host once per
+ * episode.  per_env = 0: one [D,D] table shared by all envs; 1: [B,D,D].                           */
+int d2d_set_path_loss_table(d2d_handle* h, const float* pl_db, int32_t per_env);
+
+/* Which (tx, rx) device pairs act this step and as what (Action.tx/rx/link_type, actions.py:9-15;
+ * typing rule d2d_env.py:80-91).  n_links <= max_links.  Order = agent order of the outputs.       */
+int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const int32_t* rx_dev,
+                  const int32_t* link_type);
+
+/* RewardFunction / ObsFunction plugin selection (d2d_env.py:27-28).                                */
+int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param);
+int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode);
+/* 1 (default): same-RB interferers found through per-RB membership bitmasks in LDS
+ * (Actions.get_actions_by_rb, actions.py:27-31).  0: masked all-pairs sweep.  Same results.        */
+int d2d_set_bucketing(d2d_handle* h, int32_t enabled);
+
+/* Launch-geometry knobs (performance only, results do not change).                                 */
+typedef enum d2d_tuning {
+    D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* obs rows written per workgroup; 0 = auto (~512 KiB per WG)     */
+    D2D_TUNE_OBS_NONTEMPORAL = 1,  /* 1 (default): nontemporal stores for the obs stream             */
+    D2D_TUNE_OBS_XCD_REMAP = 2     /* 1 (default): chunks of one env share an XCD                    */
+} d2d_tuning;
+int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
+
+/* ---- buffers --------------------------------------------------------------------------------- */
+/* Device pointer + size in bytes of a buffer (allocated on first use unless bound).                */
+int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes);
+/* Use caller-owned device memory for a buffer (e.g. a torch tensor); never freed by the library.   */
+int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes);
+/* Synchronous host<->device copies (ordered after queued work on the handle's stream).             */
+int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes, size_t dst_offset);
+int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset);
+/* Simulator.reset (simulator.py:61-75) with host-supplied positions: x,y [env_count, D] f32.       */
+int d2d_set_positions(d2d_handle* h, const float* x, const float* y, int32_t env_begin, int32_t env_count);
+
+/* Simulator.reset on the device (simulator.py:61-75; samplers position.py:18-45) for all B envs:
+ * BS at the origin, CUEs / DUE transmitters uniform in the cell disc, DUE receivers uniform within
+ * d2d_radius_m of their transmitter and re-drawn until inside the cell.  Counter-based Philox4x32-10
+ * stream keyed by `seed`, counter (first_env + env, device, try, episode) - see csrc/d2d_reset.hip.
+ * fixed_mask[D] / fixed_xy[D,2] (host, may be NULL): devices pinned by a device_config_file
+ * (simulator.py:65-66).  Asynchronous.                                                             */
+int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const uint8_t* fixed_mask,
+                        const float* fixed_xy);
+/* Global index of this handle's env 0 (multi-GPU sharding of one logical batch); default 0.        */
+int d2d_set_env_offset(d2d_handle* h, uint64_t first_env);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/* D2DEnv.step (d2d_env.py:62-71) for all B envs: decode -> Simulator.step (simulator.py:77-154) ->
+ * reward -> obs.  actions_dev: i32 [B,N] device pointer, or NULL to read D2D_BUF_ACTIONS.           */
+int d2d_step(d2d_handle* h, const int32_t* actions_dev);
+/* Same with (rb, tx_pwr_dBm) given explicitly - the ndarray action form (d2d_env.py:97-98).
+ * NULL pointers read D2D_BUF_RB / D2D_BUF_PWR.                                                     */
+int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev);
+/* OR of D2D_FLAG_* over all envs of the last step (synchronises the stream).                       */
+int d2d_status_flags(d2d_handle* h, uint32_t* flags);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* When enabled, every kernel launched by d2d_step is bracketed by hipEvents on the handle's stream. */
+int d2d_profile_enable(d2d_handle* h, int32_t enabled);
+/* kernel: 0 = step (decode+SINR+reward+table), 1 = LinearObs expansion.  Synchronises, then returns
+ * accumulated device time in ms and launch count since the last reset.                             */
+int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+int d2d_profile_reset(d2d_handle* h);
+/* Streaming-store probe: fills `bytes` of D2D_BUF_OBS `iters` times with 16-B stores and reports the
+ * sustained rate - the on-box write ceiling the obs kernel is compared with.                       */
+int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2D_HIP_H */

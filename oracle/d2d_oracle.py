@@ -215,18 +215,32 @@ def step(pos, link_tx, link_rx, rb, pwr, cols: DeviceColumns, spec: PathLossSpec
     out = {k: np.empty((b, n)) for k in ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps')}
     eye = np.eye(n, dtype=bool)
     noise = cols.noise_dbm[link_rx]
+    h_tx, h_rx = cols.ant_h_m[link_tx], cols.ant_h_m[link_rx]
     for s in range(0, b, chunk):
         e = min(b, s + chunk)
-        sub = PathLossSpec(**{**spec.__dict__})
-        if spec.kind == 'table' and np.asarray(spec.table_db).ndim == 3:
-            sub.table_db = spec.table_db[s:e]
-        pl = pair_path_loss_db(sub, pos[s:e], link_tx, link_rx, cols)           # [b, j, i]
+        p = pos[s:e]
         eirp = pwr[s:e] + cols.eirp_off_db[link_tx][None, :]                    # device.py:60
-        diag = pl[:, np.arange(n), np.arange(n)]
-        sig = eirp - diag + cols.rx_off_db[link_rx][None, :]                    # simulator.py:93
-        same = (rb[s:e, :, None] == rb[s:e, None, :]) & ~eye[None]              # simulator.py:95
-        ix_mw = np.where(same, db_to_linear(eirp[:, :, None] - pl), 0.0)        # simulator.py:97-101
-        sum_ix = ix_mw.sum(axis=1)
+        tab = None
+        if spec.kind == 'table':
+            tab = np.asarray(spec.table_db, dtype=np.float64)
+            tab = tab[s:e] if tab.ndim == 3 else tab[None]
+
+        def pl_of(bi, j, i):
+            """PL from the tx of link j to the rx of link i in env bi (index arrays)."""
+            if tab is not None:
+                return tab[bi if tab.shape[0] > 1 else 0, link_tx[j], link_rx[i]]
+            t = p[bi, link_tx[j]]; r = p[bi, link_rx[i]]
+            dist = ((t[..., 0] - r[..., 0]) ** 2 + (t[..., 1] - r[..., 1]) ** 2) ** 0.5   # position.py:11-12
+            return path_loss_db(spec, dist, h_tx[j], h_rx[i])
+
+        bi, ii = np.meshgrid(np.arange(e - s), np.arange(n), indexing='ij')
+        sig = eirp - pl_of(bi, ii, ii) + cols.rx_off_db[link_rx][None, :]       # simulator.py:93
+        # only links that share an RB interfere (simulator.py:95): evaluate exactly those (j -> i) pairs, like
+        # the reference's per-RB sets do, and sum them per receiver in ascending j
+        same = (rb[s:e, :, None] == rb[s:e, None, :]) & ~eye[None]              # [b, j, i]
+        pb, pj, pi = np.nonzero(same)
+        ix_mw = db_to_linear(eirp[pb, pj] - pl_of(pb, pj, pi))                  # simulator.py:97-101
+        sum_ix = np.bincount(pb * n + pi, weights=ix_mw, minlength=(e - s) * n).reshape(e - s, n)
         sinr = sig - linear_to_db(sum_ix + db_to_linear(noise)[None, :])        # simulator.py:106-107
         snr = sig - noise[None, :]                                              # simulator.py:115
         ok = sinr > cols.sens_dbm[link_rx][None, :]                             # simulator.py:123,149
@@ -281,10 +295,12 @@ def expand_obs(table):
     b, n, w = table.shape
     flat = table.reshape(b, n * w)
     out = np.empty((b, n, n * w), dtype=table.dtype)
-    for i in range(n):
-        out[:, i, :w] = table[:, i, :]
-        out[:, i, w:w * (i + 1)] = flat[:, :w * i]
-        out[:, i, w * (i + 1):] = flat[:, w * (i + 1):]
+    # slot k of agent i shows link: i (k = 0), k-1 (1 <= k <= i), k (k > i)
+    out[:] = flat[:, None, :]                                   # k > i: unshifted
+    shifted = (np.arange(1, n)[None, :] <= np.arange(n)[:, None]).repeat(w, axis=1)    # [n, (n-1)w]: 1 <= k <= i
+    if n > 1:
+        np.copyto(out[:, :, w:], flat[:, None, :-w], where=shifted[None])
+    out[:, :, :w] = table                                       # k = 0: own link
     return out
 
 
@@ -344,3 +360,35 @@ def sample_positions_from_uniforms(u, num_cues, num_due_pairs, cell_radius_m=500
         if not done.all():
             raise RuntimeError('rejection sampler ran out of tries')
     return pos, used
+
+
+# --------------------------------------------------------------------------- counter-based RNG (reset path)
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: 'Parallel random numbers: as easy as 1, 2, 3', SC'11), the
+    stream csrc/d2d_reset.hip uses.  Inputs broadcastable uint arrays; returns 4 uint32 arrays."""
+    c = [np.asarray(v, dtype=np.uint64) & _MASK32 for v in (c0, c1, c2, c3)]
+    c = list(np.broadcast_arrays(*c))
+    k0 = int(k0) & 0xFFFFFFFF; k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _PHILOX_M0 * c[0]; p1 = _PHILOX_M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0 = (k0 + _PHILOX_W0) & 0xFFFFFFFF; k1 = (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return [v.astype(np.uint32) for v in c]
+
+
+def reset_uniforms(seed, episode, num_envs, num_devices, tries, first_env=0):
+    """The uniforms the device-side reset consumes: u[b, d, t, 0] -> theta, u[b, d, t, 1] -> radius, each
+    (word >> 8) * 2^-24 with counter (first_env + b, d, t, episode) and key = 64-bit seed."""
+    b = (np.arange(num_envs, dtype=np.uint64) + np.uint64(first_env))[:, None, None]
+    d = np.arange(num_devices, dtype=np.uint64)[None, :, None]
+    t = np.arange(tries, dtype=np.uint64)[None, None, :]
+    w = philox4x32_10(b, d, t, np.uint64(episode & 0xFFFFFFFF), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    scale = 2.0 ** -24
+    return np.stack([(w[0] >> np.uint32(8)) * scale, (w[1] >> np.uint32(8)) * scale], axis=-1)

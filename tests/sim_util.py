@@ -1,0 +1,77 @@
+"""Helpers shared by the GPU parity tests: build a gym_d2d_amd Simulator / D2DEnv that mirrors a golden case."""
+import math
+from pathlib import Path
+
+import numpy as np
+
+from golden_util import GOLDEN_DIR
+from oracle import d2d_oracle as orc
+
+
+def path_loss_class(case_meta):
+    from gym_d2d_amd.path_loss import (AreaType, CostHataPathLoss, LogDistancePathLoss, PathLoss)
+    pl = case_meta['path_loss']
+    if pl['kind'] == 'log_distance':
+        if pl['ple'] == 2.0:
+            return LogDistancePathLoss
+        ple = pl['ple']
+
+        class Ple(LogDistancePathLoss):
+            def __init__(self, f):
+                super().__init__(f, ple=ple)
+        return Ple
+    if pl['kind'] == 'cost_hata':
+        area = {'urban': AreaType.URBAN, 'suburban': AreaType.SUBURBAN, 'rural': AreaType.RURAL}[pl['area']]
+
+        class Hata(CostHataPathLoss):
+            def __init__(self, f):
+                super().__init__(f, area)
+        return Hata
+    if pl['kind'] == 'custom_foo':
+        class FooPathLoss(PathLoss):           # user-defined plugin in the style of examples/custom_path_loss.py
+            def __call__(self, tx, rx):
+                d = tx.position.distance(rx.position)
+                return 20 * math.log10(d) - tx.tx_antenna_gain_dBi - rx.rx_antenna_gain_dBi
+        return FooPathLoss
+    raise AssertionError(pl)
+
+
+def env_config_for(case, **extra):
+    m = case.meta
+    cfg = {k: m[k] for k in ('num_rbs', 'num_cues', 'num_due_pairs', 'cell_radius_m', 'd2d_radius_m',
+                             'due_min_tx_power_dBm', 'due_max_tx_power_dBm', 'cue_max_tx_power_dBm',
+                             'mbs_max_tx_power_dBm', 'carrier_freq_GHz', 'num_subcarriers', 'subcarrier_spacing_kHz')}
+    cfg['path_loss_model'] = path_loss_class(m)
+    if case.name == 'case07_device_config':
+        cfg['device_config_file'] = GOLDEN_DIR / 'case07_device_config.json'
+    cfg.update(extra)
+    return cfg
+
+
+def oracle_spec(case, cols=None):
+    pl = case.meta['path_loss']
+    f = case.meta['carrier_freq_GHz']
+    if pl['kind'] == 'log_distance':
+        return orc.PathLossSpec('log_distance', f, ple=pl['ple'])
+    if pl['kind'] == 'cost_hata':
+        return orc.PathLossSpec('cost_hata', f, area=pl['area'])
+    cols = cols or orc.device_columns(case.cfgs, case.is_bs)
+    d = np.hypot(case.pos[:, None, 0] - case.pos[None, :, 0], case.pos[:, None, 1] - case.pos[None, :, 1])
+    with np.errstate(divide='ignore'):
+        table = 20 * np.log10(d) - cols.tx_gain_dbi[:, None] - cols.rx_gain_dbi[None, :]
+    return orc.PathLossSpec('table', f, table_db=table)
+
+
+def random_layout(rng, num_envs, num_cues, num_due_pairs, cell_radius=500.0, d2d_radius=20.0):
+    """float32-representable positions [B, D, 2] from the oracle's sampler."""
+    d = 1 + num_cues + 2 * num_due_pairs
+    u = rng.random((num_envs, d, 32, 2))
+    pos, _ = orc.sample_positions_from_uniforms(u, num_cues, num_due_pairs, cell_radius, d2d_radius)
+    return pos.astype(np.float32)
+
+
+def default_links(num_cues, num_due_pairs):
+    tx = list(range(1, 1 + num_cues)) + [1 + num_cues + 2 * p for p in range(num_due_pairs)]
+    rx = [0] * num_cues + [2 + num_cues + 2 * p for p in range(num_due_pairs)]
+    ty = [orc.UPLINK] * num_cues + [orc.SIDELINK] * num_due_pairs
+    return np.array(tx), np.array(rx), np.array(ty)
