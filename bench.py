@@ -181,6 +181,15 @@ def main():
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'avg_launch_ms': step_ms / max(step_n, 1),
                     'algorithmic_bytes_per_launch': per_launch, 'traffic': None}
         roof['frac'] = roof['achieved'] / roof['peak']
+        # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process): taken from
+        # the committed summary of the same workload, when one exists for this kernel
+        pmc = sorted((ROOT / 'profiles').glob('r*_pmc_hbm_traffic.json'))
+        if pmc and args.workload == 'stress' and not args.envs:
+            rec = json.loads(pmc[-1].read_text())
+            for kname, d in rec['kernels'].items():
+                if roof['kernel'] in kname:
+                    roof['traffic'] = d['hbm_bytes_per_launch']
+                    roof['traffic_source'] = f'profiles/{pmc[-1].name} (WRITE_SIZE + 2*FETCH_SIZE, separate --pmc passes)'
         out = {
             'metric': 'env agent-steps/sec (batch x agents)', 'value': value, 'unit': 'agent-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,

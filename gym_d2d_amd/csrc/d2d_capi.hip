@@ -62,7 +62,7 @@ struct d2d_handle {
     float reward_param = 0.0f;
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
-    int tune_rows = 0, tune_nt = 1, tune_xcd = 1;
+    int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0;
     unsigned long long env_offset = 0;
     unsigned char* fixed_mask_dev = nullptr;   // [D] + pad
     float* fixed_xy_dev = nullptr;             // [D,2]
@@ -212,7 +212,6 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.status = h->status;
 
     EventPair* ep = nullptr;
-    HIP_TRY(hipMemsetAsync(h->status, 0, 4, h->stream));
     rc = record_start(h, 0, &ep);
     if (rc) return rc;
     HIP_TRY(d2d::launch_step(s, h->mode, h->stream));
@@ -225,19 +224,27 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         o.vec = (6 * N) % 4 == 0 ? 4 : 2;
         o.q_per_row = (unsigned)(6 * N / o.vec);
         o.q_magic = ((1ull << 40) + o.q_per_row - 1) / o.q_per_row;
+        // Launch geometry (tools/tune_obs.py, MI355X, N = 512): the fastest shape is the one where every thread
+        // issues exactly TWO 16-B stores - block = one row's float4 count (768), 2 rows per workgroup: 6.96 TB/s vs
+        // 5.9 TB/s for 96-KiB slabs and 5.6 TB/s for 786-KiB slabs.  Small slabs dispatched in order keep the
+        // chip-wide write front nearly sequential in address, and a workgroup never outlives its neighbours.
+        int block = h->tune_block;
+        if (block <= 0) {
+            block = (int)((o.q_per_row + 63) / 64) * 64;
+            if (block < 256) block = 256;
+            if (block > 1024) block = 1024;
+        }
         int rows = h->tune_rows;
         if (rows <= 0) {
-            rows = (int)((512 * 1024) / ((size_t)24 * N));
+            rows = (int)((2u * (unsigned)block + o.q_per_row / 2) / o.q_per_row);
             if (rows < 1) rows = 1;
-            if (rows > N) rows = N;
-            for (int r = rows; r > rows / 2 && r >= 1; --r)
-                if (N % r == 0) { rows = r; break; }
         }
         if (rows > N) rows = N;
         o.rows_per_wg = rows;
         o.chunks = (N + rows - 1) / rows;
         o.xcd_remap = h->tune_xcd && (h->B % 8 == 0);
         o.nontemporal = h->tune_nt;
+        o.block = block;
         o.table = s.table;
         rc = ensure_buffer(h, D2D_BUF_OBS, &p);
         if (rc) return rc;
@@ -436,6 +443,10 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
         case D2D_TUNE_OBS_ROWS_PER_WG: h->tune_rows = value; break;
         case D2D_TUNE_OBS_NONTEMPORAL: h->tune_nt = value ? 1 : 0; break;
         case D2D_TUNE_OBS_XCD_REMAP: h->tune_xcd = value ? 1 : 0; break;
+        case D2D_TUNE_OBS_BLOCK:
+            if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "block must be a multiple of 64 in [64,1024]");
+            h->tune_block = value;
+            break;
         default: return fail(D2D_ERR_INVALID, "unknown tuning key");
     }
     return D2D_OK;
@@ -544,6 +555,8 @@ int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev
 
 int d2d_status_flags(d2d_handle* h, uint32_t* flags) {
     if (!h || !flags) return fail(D2D_ERR_INVALID, "null argument");
+    if (!h->buf[D2D_BUF_ENV_FLAGS].ptr) { *flags = 0; return D2D_OK; }
+    HIP_TRY(d2d::launch_flags_or(static_cast<const int*>(h->buf[D2D_BUF_ENV_FLAGS].ptr), h->B, h->status, h->stream));
     HIP_TRY(hipMemcpyAsync(flags, h->status, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return D2D_OK;

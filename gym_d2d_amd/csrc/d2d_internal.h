@@ -63,6 +63,7 @@ struct ObsArgs {
     unsigned long long q_magic;  // ceil(2^40 / q_per_row)
     int xcd_remap;
     int nontemporal;
+    int block;               // threads per workgroup (0 -> 256)
     const float* table;      // [B,N,6]
     float* obs;              // [B,N,6N]
 };
@@ -71,6 +72,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream);
 size_t step_lds_bytes(int N, int R, int mask_words);
+hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);
 hipError_t launch_reset(int B, int D, int C, float cell_radius, float d2d_radius, unsigned long long seed,
                         unsigned long long episode, unsigned long long env_offset, const unsigned char* fixed_mask,
                         const float* fixed_xy, float* pos_x, float* pos_y, hipStream_t stream);

@@ -28,9 +28,9 @@ __device__ __forceinline__ unsigned src_col(unsigned f, unsigned i) {
 }
 
 template <int VEC, bool NT>
-__global__ __launch_bounds__(256) void obs_expand_kernel(const ObsArgs a) {
+__global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     extern __shared__ __align__(16) float t_flat[];          // [6N]
-    const unsigned N = a.N, tid = threadIdx.x;
+    const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
     unsigned env, chunk;
     if (a.xcd_remap) {
         // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give them the chunks of ONE env
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void obs_expand_kernel(const ObsArgs a) {
     {
         const f32x2* src = reinterpret_cast<const f32x2*>(a.table + (size_t)env * row_floats);
         f32x2* dst = reinterpret_cast<f32x2*>(t_flat);
-        for (unsigned k = tid; k < row_floats / 2; k += 256) dst[k] = src[k];
+        for (unsigned k = tid; k < row_floats / 2; k += T) dst[k] = src[k];
     }
     __syncthreads();
 
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void obs_expand_kernel(const ObsArgs a) {
     float* out = a.obs + ((size_t)env * N + r0) * row_floats;   // contiguous slab of rows [r0, r1)
 
 #pragma unroll 4
-    for (unsigned idx = tid; idx < total; idx += 256) {
+    for (unsigned idx = tid; idx < total; idx += T) {
         const unsigned lr = (unsigned)(((unsigned long long)idx * a.q_magic) >> 40);   // idx / q_per_row
         const unsigned q = idx - lr * q_per_row;
         const unsigned i = r0 + lr;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void obs_expand_kernel(const ObsArgs a) {
 
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.N * 6 * sizeof(float);
-    dim3 grid((unsigned)a.B * (unsigned)a.chunks), block(256);
+    dim3 grid((unsigned)a.B * (unsigned)a.chunks), block(a.block > 0 ? a.block : 256);
     if (a.vec == 4) {
         if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<4, true>), grid, block, lds, stream, a);
         else hipLaunchKernelGGL((obs_expand_kernel<4, false>), grid, block, lds, stream, a);
@@ -90,20 +90,24 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Streaming-store probe: the on-box ceiling for a write-only 16-B/lane stream (d2d_probe_write_bandwidth).
-__global__ __launch_bounds__(256) void fill_kernel(f32x4* dst, size_t n, float value) {
+// Streaming-store probe (d2d_probe_write_bandwidth): the same store pattern as the obs kernel - every workgroup
+// writes one contiguous slab with 16-B nontemporal stores - but with no LDS reads and no index arithmetic.  It is
+// the on-box ceiling the obs kernel is compared with.
+__global__ __launch_bounds__(256) void fill_kernel(f32x4* dst, size_t n, unsigned slab, float value) {
     const f32x4 v = {value, value, value, value};
-    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t base = (size_t)blockIdx.x * slab;
+    const unsigned count = (unsigned)(n - base < slab ? n - base : slab);
+    f32x4* p = dst + base;
 #pragma unroll 4
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) __builtin_nontemporal_store(v, dst + k);
+    for (unsigned k = threadIdx.x; k < count; k += 256) __builtin_nontemporal_store(v, p + k);
 }
 
 hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream) {
-    size_t blocks = (n_float4 + 255) / 256;
-    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+    const unsigned slab = 6144;     // 96 KiB per workgroup = 8 obs rows at N = 512
+    const size_t blocks = (n_float4 + slab - 1) / slab;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<f32x4*>(dst),
-                       n_float4, value);
+                       n_float4, slab, value);
     return hipGetLastError();
 }
 

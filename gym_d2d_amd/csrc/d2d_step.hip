@@ -283,11 +283,26 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         __syncthreads();
     }
 
-    if (tid == 0) {
-        const int f = s.flags[0];
-        a.env_flags[b] = f;
-        if (f) atomicOr(a.status, (unsigned)f);
-    }
+    if (tid == 0) a.env_flags[b] = s.flags[0];
+}
+
+// OR-reduction of the per-env flag words, run only when the host asks (d2d_status_flags): keeps the memset +
+// atomic out of the per-step stream.
+__global__ __launch_bounds__(256) void flags_or_kernel(const int* env_flags, int B, unsigned* status) {
+    unsigned f = 0;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < B; k += gridDim.x * 256) f |= (unsigned)env_flags[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+    if ((threadIdx.x & 63) == 0 && f) atomicOr(status, f);
+}
+
+hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(status, 0, 4, stream);
+    if (err != hipSuccess) return err;
+    int blocks = (B + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(flags_or_kernel, dim3(blocks), dim3(256), 0, stream, env_flags, B, status);
+    return hipGetLastError();
 }
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream) {

@@ -144,7 +144,8 @@ int d2d_set_bucketing(d2d_handle* h, int32_t enabled);
 typedef enum d2d_tuning {
     D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* obs rows written per workgroup; 0 = auto (~512 KiB per WG)     */
     D2D_TUNE_OBS_NONTEMPORAL = 1,  /* 1 (default): nontemporal stores for the obs stream             */
-    D2D_TUNE_OBS_XCD_REMAP = 2     /* 1 (default): chunks of one env share an XCD                    */
+    D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
+    D2D_TUNE_OBS_BLOCK = 3         /* threads per obs workgroup; 0 = default (256)                   */
 } d2d_tuning;
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
 
