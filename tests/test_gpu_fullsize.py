@@ -1,0 +1,101 @@
+"""BASELINE-size checks (4096 envs x 512 links, obs materialised: 25.8 GB) through properties that do not need the
+oracle to finish at that size, plus sampled envs against the oracle.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from golden_util import rel_err
+from oracle import d2d_oracle as orc
+from sim_util import default_links
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+B, C, P, R = 4096, 256, 256, 256
+N = C + P
+
+
+@pytest.fixture(scope='module')
+def big_env():
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    if not torch.cuda.is_available():
+        pytest.skip('needs torch + GPU')
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip('needs 40 GB of free HBM')
+    env = VecD2DEnv({'num_rbs': R, 'num_cues': C, 'num_due_pairs': P}, num_envs=B)
+    yield env
+    env.close()
+
+
+def _actions(torch, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    a = torch.empty((B, N), dtype=torch.int32, device=device)
+    a[:, :C] = torch.randint(0, R * 24, (B, C), generator=g, device=device, dtype=torch.int32)
+    a[:, C:] = torch.randint(0, R * 21, (B, P), generator=g, device=device, dtype=torch.int32)
+    return a
+
+
+def test_full_size_step_properties(big_env):
+    import torch
+    env = big_env
+    obs = env.reset(seed=2024)
+    assert tuple(obs.shape) == (B, N, 6 * N) and obs.dtype == torch.float32
+    act = _actions(torch, obs.device, 7)
+    obs, rew, dones, info = env.step(act)
+    torch.cuda.synchronize()
+    assert env.status_flags() == 0
+    table = env._t['table']
+    # (1) obs layout identity on EVERY element: obs[b,i] = (T[i], T[0..i-1], T[i+1..]) - bit exact, in chunks
+    i = torch.arange(N, device=obs.device)[:, None]
+    k = torch.arange(N, device=obs.device)[None, :]
+    src = torch.where(k == 0, i, torch.where(k <= i, k - 1, k))             # [N, N] source link per slot
+    for s in range(0, B, 64):
+        want = table[s:s + 64][:, src, :].reshape(-1, N, 6 * N)
+        assert torch.equal(obs[s:s + 64], want), f'obs layout mismatch in envs {s}..{s + 64}'
+        del want
+    # (2) every obs row is a permutation of the env's table: row sums agree (fp64 accumulate)
+    tot = table.double().sum(dim=(1, 2))
+    rows = obs[::97].double().sum(dim=2)
+    assert torch.allclose(rows, tot[::97, None].expand_as(rows), rtol=1e-9, atol=1e-6)
+    # (3) reward is one scalar per env, equal to mean capacity (no violation can occur at min_capacity 0)
+    cap = info['capacity_mbps']
+    assert torch.equal(rew, rew[:, :1].expand_as(rew))
+    assert torch.allclose(rew[:, 0].double(), cap.double().mean(dim=1), rtol=2e-6)
+    # (4) determinism: same inputs -> same bits
+    sinr1 = info['sinr_db'].clone(); chk1 = obs[::511].clone()
+    obs2, rew2, _, info2 = env.step(act)
+    assert torch.equal(info2['sinr_db'], sinr1) and torch.equal(obs2[::511], chk1)
+    # (5) decode identity on all 2M links
+    assert torch.equal(info['rb'][:, :C], act[:, :C] // 24) and torch.equal(info['tx_pwr_dbm'][:, C:], act[:, C:] % 21)
+    # (6) sampled envs against the fp64 oracle
+    pick = np.array([0, 1, 777, 2048, 4095])
+    pos = env.simulator.positions()[pick].astype(np.float64)
+    tx, rx, ty = default_links(C, P)
+    ids, cfgs, is_bs = orc.device_configs(C, P)
+    cols = orc.device_columns(cfgs, is_bs)
+    ref = orc.full_step(pos, tx, rx, ty, act[pick].cpu().numpy(), cols, orc.PathLossSpec(), chunk=8)
+    for f in ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps'):
+        assert rel_err(info[f][pick].cpu().numpy(), ref[f]) <= TOL, f
+    assert rel_err(obs[pick].cpu().numpy(), ref['obs']) <= TOL
+    assert rel_err(rew[pick, 0].cpu().numpy(), ref['reward']) <= TOL
+
+
+def test_full_size_reset_properties(big_env):
+    import torch
+    env = big_env
+    env.reset(seed=99)
+    x, y = env._t['pos_x'], env._t['pos_y']
+    r = torch.hypot(x, y)
+    assert float(r.max()) <= 500.0 * (1 + 1e-6) and bool((r[:, 0] == 0).all())
+    tx = slice(1 + C, None, 2); rxs = slice(2 + C, None, 2)
+    d = torch.hypot(x[:, tx] - x[:, rxs], y[:, tx] - y[:, rxs])
+    assert float(d.max()) <= 20.0 * (1 + 1e-5) and float(d.min()) > 0.0
+    # uniform over the disc: E[r^2] = R^2/2; 1M CUE samples -> 0.1 % tolerance is > 10 sigma
+    cue = r[:, 1:1 + C].double()
+    assert abs(float((cue ** 2).mean()) / (500.0 ** 2 / 2) - 1.0) < 2e-3
+    # envs differ, episodes differ
+    assert not torch.equal(x[0], x[1])
+    x0 = x.clone()
+    env.reset()
+    assert not torch.equal(env._t['pos_x'], x0)
