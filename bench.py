@@ -74,6 +74,7 @@ def main():
     ap.add_argument('--envs', type=int, default=0, help='override envs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the per-step all-gather')
+    ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
     ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket')
     args = ap.parse_args()
 
@@ -86,10 +87,12 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from gym_d2d_amd import _native
     from gym_d2d_amd.envs import VecD2DEnv
@@ -126,7 +129,7 @@ def main():
         actions[:, :, c:] = torch.randint(0, r * pd, (total, b, p), generator=g, device=dev, dtype=torch.int32)
 
     gatherer = None
-    if world > 1 and not args.no_gather:
+    if use_dist and not args.no_gather:
         from gym_d2d_amd.distributed import StepGatherer
         gatherer = StepGatherer(b, n, dev)
 
@@ -140,7 +143,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -157,7 +160,7 @@ def main():
     h.profile_enable(False)
     flags = env.status_flags()
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -207,7 +210,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

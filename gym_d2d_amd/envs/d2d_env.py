@@ -139,7 +139,10 @@ class D2DEnv(Env):
         if isinstance(action, (int, np.integer)):
             rb, pwr = divmod(int(action), self.num_pwr_actions[tx_type])
         elif isinstance(action, np.ndarray) and action.ndim == 2:
-            rb, pwr = action
+            rb, pwr = (np.asarray(part) for part in action)
+            if rb.size != 1 or pwr.size != 1:
+                raise TypeError('only size-1 arrays can be converted to Python scalars')
+            rb, pwr = rb.item(), pwr.item()
         else:
             raise ValueError(f'Unable to decode action type "{type(action)}"')
         return int(rb), int(pwr)
