@@ -62,6 +62,7 @@ SIGNATURES = {
     'd2d_set_device_table': (C.c_int, [_P, _I, _DP, _DP, _DP, _DP, _DP]),
     'd2d_set_path_loss_power_law': (C.c_int, [_P, _I, _DP, _DP, _DP]),
     'd2d_set_path_loss_table': (C.c_int, [_P, _FP, _I]),
+    'd2d_set_path_loss_shadowing': (C.c_int, [_P, _I, _DP, _DP, _DP, C.c_double, C.c_double, C.c_uint64]),
     'd2d_set_links': (C.c_int, [_P, _I, _IP, _IP, _IP]),
     'd2d_set_reward': (C.c_int, [_P, _I, C.c_float]),
     'd2d_set_obs_mode': (C.c_int, [_P, _I]),
@@ -156,6 +157,11 @@ class Handle:
     def set_path_loss_power_law(self, a_tx_db, a_rx_db, exponent) -> None:
         cols = [np.ascontiguousarray(c, dtype=np.float64) for c in (a_tx_db, a_rx_db, exponent)]
         _check(self._lib.d2d_set_path_loss_power_law(self._h, len(cols[0]), *[_dptr(c) for c in cols]))
+
+    def set_path_loss_shadowing(self, a_tx_db, a_rx_db, exponent, d0_m: float, chi_db: float, seed: int) -> None:
+        cols = [np.ascontiguousarray(c, dtype=np.float64) for c in (a_tx_db, a_rx_db, exponent)]
+        _check(self._lib.d2d_set_path_loss_shadowing(self._h, len(cols[0]), *[_dptr(c) for c in cols],
+                                                     float(d0_m), float(chi_db), C.c_uint64(seed)))
 
     def set_path_loss_table(self, pl_db: np.ndarray) -> None:
         t = np.ascontiguousarray(pl_db, dtype=np.float32)

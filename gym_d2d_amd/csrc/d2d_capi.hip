@@ -64,6 +64,8 @@ struct d2d_handle {
     int bucketing = 1;
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0;
     unsigned long long env_offset = 0;
+    double shadow_chi = 0, shadow_d0 = 0;
+    unsigned long long shadow_seed = 0, shadow_step = 0;
     unsigned char* fixed_mask_dev = nullptr;   // [D] + pad
     float* fixed_xy_dev = nullptr;             // [D,2]
     // profiling
@@ -121,7 +123,7 @@ int refresh_tables(d2d_handle* h) {
         cols[6 * D + d] = h->mode == d2d::PL_TABLE ? 2.0f : (float)h->expo[d];
         if (h->mode != d2d::PL_TABLE && h->expo[d] != 2.0) all_two = false;
     }
-    if (h->mode != d2d::PL_TABLE) h->mode = all_two ? d2d::PL_INV_SQUARE : d2d::PL_POWER;
+    if (h->mode != d2d::PL_TABLE && h->mode != d2d::PL_SHADOW) h->mode = all_two ? d2d::PL_INV_SQUARE : d2d::PL_POWER;
     HIP_TRY(hipMemcpyAsync(h->dev_cols, cols.data(), cols.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // cols is a stack-lifetime host buffer
     h->tables_dirty = false;
@@ -209,6 +211,14 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.pow10_tab = h->pow10_tab;
     s.gain_table = h->gain_table;
     s.table_env_stride = h->table_per_env ? (long long)D * D : 0;
+    s.env_offset = h->env_offset;
+    if (h->mode == d2d::PL_SHADOW) {
+        s.shadow_chi = (float)h->shadow_chi;
+        s.shadow_d0sq = (float)(h->shadow_d0 * h->shadow_d0);
+        s.shadow_seed_lo = (unsigned)(h->shadow_seed & 0xFFFFFFFFull);
+        s.shadow_seed_hi = (unsigned)(h->shadow_seed >> 32);
+        s.shadow_step = (unsigned)h->shadow_step++;
+    }
     s.status = h->status;
 
     EventPair* ep = nullptr;
@@ -374,6 +384,16 @@ int d2d_set_path_loss_power_law(d2d_handle* h, int32_t n_dev, const double* a_tx
     h->expo.assign(exponent, exponent + n_dev);
     h->mode = d2d::PL_POWER;   // refined to PL_INV_SQUARE in refresh_tables when every exponent is 2
     h->have_pl = true; h->tables_dirty = true;
+    return D2D_OK;
+}
+
+int d2d_set_path_loss_shadowing(d2d_handle* h, int32_t n_dev, const double* a_tx_db, const double* a_rx_db,
+                                const double* exponent, double d0_m, double chi_db, uint64_t seed) {
+    if (!(d0_m >= 0.0) || !(chi_db >= 0.0)) return fail(D2D_ERR_INVALID, "d0_m and chi_db must be >= 0");
+    int rc = d2d_set_path_loss_power_law(h, n_dev, a_tx_db, a_rx_db, exponent);
+    if (rc) return rc;
+    h->mode = d2d::PL_SHADOW;
+    h->shadow_d0 = d0_m; h->shadow_chi = chi_db; h->shadow_seed = seed; h->shadow_step = 0;
     return D2D_OK;
 }
 

@@ -9,7 +9,8 @@ namespace d2d {
 enum PlMode : int {
     PL_INV_SQUARE = 0,   // every exponent == 2 (LogDistance default / FreeSpace): gain = k / d^2, one v_rcp
     PL_POWER = 1,        // per-tx exponent (ple != 2, COST-Hata): gain = k * (d^2)^(-e/2)
-    PL_TABLE = 2         // host-evaluated [D,D] (or [B,D,D]) linear gain table
+    PL_TABLE = 2,        // host-evaluated [D,D] (or [B,D,D]) linear gain table
+    PL_SHADOW = 3        // PL_POWER + log-normal shadowing beyond d0, fresh Philox Gaussian per evaluation
 };
 
 struct StepArgs {
@@ -41,6 +42,11 @@ struct StepArgs {
     const float* pow10_tab;    // [128] 10^(p/10) for integer p dBm
     const float* gain_table;   // PL_TABLE: linear gain [D,D] (tx major)
     long long table_env_stride; // 0 or D*D
+    // PL_SHADOW (ShadowingPathLoss, path_loss.py:69-81)
+    float shadow_chi;        // std of the shadowing term, dB
+    float shadow_d0sq;       // (close-in reference distance)^2
+    unsigned shadow_seed_lo, shadow_seed_hi, shadow_step;
+    unsigned long long env_offset;
     // outputs
     int* rb_out;             // [B,N] (nullable)
     int* pwr_out;

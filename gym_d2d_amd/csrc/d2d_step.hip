@@ -62,6 +62,33 @@ __device__ __forceinline__ float pair_gain(float d2, float e) {
     return pow_neg_half(d2, e);
 }
 
+// Philox4x32-10 (same generator as csrc/d2d_reset.hip), used for the per-call Gaussian of ShadowingPathLoss.
+__device__ __forceinline__ void philox_step(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                            unsigned& o0, unsigned& o1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1;
+}
+
+// Linear-domain factor 10^(-X/10), X ~ N(0, chi^2) dB, for the call (tx link j -> rx link i, kind) of this step.
+// ShadowingPathLoss.__call__ draws gauss(0, chi) on EVERY call with d > d0 (path_loss.py:76-79): the signal term of
+// the SINR (kind 0, j == i), every interferer term (kind 0, j != i) and the SNR's own re-evaluation of the signal
+// path loss (kind 1, simulator.py:114) are independent draws.
+__device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, int j, int i, unsigned kind) {
+    unsigned w0, w1;
+    philox_step(env, a.shadow_step, (unsigned)j | ((unsigned)i << 16), kind, a.shadow_seed_lo, a.shadow_seed_hi, w0, w1);
+    const float u1 = ((float)(w0 >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1)
+    const float u2 = (float)(w1 >> 8) * 5.9604644775390625e-08f;               // [0, 1)
+    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+    return exp2f(-0.33219280948873623f * a.shadow_chi * z);                     // 10^(-chi z / 10)
+}
+
 // LDS carve-up.  44 bytes per link + masks.
 struct Smem {
     float4* link;   // [N] tx_x, tx_y, effective tx power (mW, incl. tx side of the PL constant), rb bits
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         s.link[i] = make_float4(px[txd], py[txd], p10 * a.dev_tx_lin[txd], __int_as_float(rb));
         s.rx[i] = make_float2(px[rxd], py[rxd]);
         s.aux[i] = txd | (type << 24);
-        if (MODE == PL_POWER) s.expo[i] = a.dev_exp[txd];
+        if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = a.dev_exp[txd];
         if (a.rb_out) { a.rb_out[row + i] = rb; a.pwr_out[row + i] = p; }
         if (want_masks) {
             const u64 bit = 1ull << (i & 63);
@@ -147,6 +174,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     __syncthreads();
     const bool use_masks = want_masks && !(s.flags[0] & FLAG_RB_OOR);
     const float* gtab = MODE == PL_TABLE ? a.gain_table + (size_t)b * a.table_env_stride : nullptr;
+    const unsigned genv = (unsigned)(a.env_offset + (unsigned long long)b);   // global env index (RNG counter)
 
     // ---- pass 2: interference reduction + SINR/SNR/rate/capacity + obs table
     float cap_part = 0.0f;
@@ -173,7 +201,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     const float d2 = fmaf(dx, dx, dy * dy);
                     float g;
                     if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
-                    else { g = pair_gain<MODE>(d2, MODE == PL_POWER ? s.expo[j] : 2.0f); zero |= d2 == 0.0f; }
+                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); zero |= d2 == 0.0f; }
+                    if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                     acc = fmaf(o.z, g, acc);                             // simulator.py:97-101, linear mW
                 }
             }
@@ -186,7 +215,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
-                else { g = pair_gain<MODE>(d2, MODE == PL_POWER ? s.expo[j] : 2.0f); zero |= same & (d2 == 0.0f); }
+                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); zero |= same & (d2 == 0.0f); }
+                if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                 acc = same ? fmaf(o.z, g, acc) : acc;
             }
         }
@@ -196,14 +226,19 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
-        else { g = pair_gain<MODE>(d2, MODE == PL_POWER ? s.expo[i] : 2.0f); zero |= d2 == 0.0f; }
+        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[i] : 2.0f); zero |= d2 == 0.0f; }
         const float rx_pl = a.dev_rx_pl[rxd];
-        const float sig = me.z * g * rx_pl * a.dev_rx_lin[rxd];          // mW at the receiver, with rx gains
+        float sig = me.z * g * rx_pl * a.dev_rx_lin[rxd];                // mW at the receiver, with rx gains
+        float sig_snr = sig;
+        if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
+            sig_snr = sig * shadow_factor(a, genv, i, i, 1u);            // simulator.py:114: a second, independent draw
+            sig *= shadow_factor(a, genv, i, i, 0u);                     // simulator.py:93
+        }
         const float ix = acc * rx_pl;                                    // interferers: no rx gains (simulator.py:100)
         const float noise = a.dev_noise_mw[rxd];
         const float sinr_lin = sig / (ix + noise);
         const float sinr_db = 10.0f * log10f(sinr_lin);                  // simulator.py:106-107
-        const float snr_db = 10.0f * log10f(sig / noise);                // simulator.py:115
+        const float snr_db = 10.0f * log10f(sig_snr / noise);            // simulator.py:115
         const float sh = log1pf(sinr_lin) * 1.44269504088896340736f;     // log2(1 + sinr)
         const bool ok = sinr_db > a.dev_sens_db[rxd];                    // simulator.py:123,149
         const float rate = ok ? sh : 0.0f;
@@ -326,6 +361,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream) {
         case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;
         case PL_POWER: D2D_LAUNCH(PL_POWER); break;
         case PL_TABLE: D2D_LAUNCH(PL_TABLE); break;
+        case PL_SHADOW: D2D_LAUNCH(PL_SHADOW); break;
     }
 #undef D2D_LAUNCH
     return err;

@@ -77,7 +77,7 @@ class LogDistancePathLoss(PathLoss):
         return self._log_distance_path_loss(tx.position.distance(rx.position))
 
     def power_law_columns(self, devices):
-        if type(self).__call__ is not LogDistancePathLoss.__call__:
+        if type(self).__call__ not in (LogDistancePathLoss.__call__, getattr(ShadowingPathLoss, '__call__', None)):
             return None     # a subclass changed the formula: evaluate it on the host instead
         n = len(devices)
         return {'a_tx_db': np.full(n, self.pl_constant_dB), 'a_rx_db': np.zeros(n), 'exponent': np.full(n, self.ple)}
@@ -108,8 +108,15 @@ class ShadowingPathLoss(LogDistancePathLoss):
         return anchor + 10 * self.ple * math.log10(d / self.d0_m) + gauss(0, self.chi_dB)
 
     def power_law_columns(self, devices):
-        raise NotImplementedError('ShadowingPathLoss draws a new Gaussian per call; its device-side RNG route is '
-                                  'not built yet (SURVEY.md 8(f) rank 3)')
+        if type(self).__call__ is not ShadowingPathLoss.__call__:
+            return None
+        cols = LogDistancePathLoss.power_law_columns(self, devices) if \
+            type(self)._log_distance_path_loss is LogDistancePathLoss._log_distance_path_loss else None
+        if cols is not None:
+            # LD(d0) + 10 n log10(d/d0) == LD(d): the deterministic part is the plain log-distance law; the kernel
+            # adds the per-evaluation Gaussian beyond d0 (csrc/d2d_step.hip, PL_SHADOW)
+            cols['shadowing'] = {'d0_m': self.d0_m, 'chi_dB': self.chi_dB}
+        return cols
 
 
 class AreaType(Enum):

@@ -8,6 +8,7 @@ implementation of the step: without libd2d_hip.so and a gfx950 GPU, construction
 """
 from __future__ import annotations
 
+import random
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -103,7 +104,14 @@ class Simulator:
                                      cols['bw_hz'])
         law = self.path_loss.power_law_columns(self._dev_list)
         if law is not None:
-            self.handle.set_path_loss_power_law(law['a_tx_db'], law['a_rx_db'], law['exponent'])
+            shadow = law.get('shadowing')
+            if shadow:
+                seed = self.config.seed if self.config.seed is not None else random.getrandbits(63)
+                self.handle.set_path_loss_shadowing(law['a_tx_db'], law['a_rx_db'], law['exponent'], shadow['d0_m'],
+                                                    shadow['chi_dB'], seed)
+                self.shadowing_seed = seed
+            else:
+                self.handle.set_path_loss_power_law(law['a_tx_db'], law['a_rx_db'], law['exponent'])
             self._table_route = False
         else:
             self._table_route = True    # evaluated per episode in _refresh_path_loss_table()

@@ -123,6 +123,13 @@ int d2d_set_device_table(d2d_handle* h, int32_t n_dev, const double* eirp_off_db
 int d2d_set_path_loss_power_law(d2d_handle* h, int32_t n_dev, const double* a_tx_db, const double* a_rx_db,
                                 const double* exponent);
 
+/* ShadowingPathLoss (path_loss.py:69-81): the power law above plus gauss(0, chi_db) dB on EVERY evaluation with
+ * distance > d0_m - SINR signal term, each interferer term and the SNR's re-evaluation are independent
+ * draws, as in the reference.  Draws come from Philox4x32-10 keyed by `seed` with counter
+ * (global env, step, tx link | rx link << 16, kind); `step` counts d2d_step* calls since this call.   */
+int d2d_set_path_loss_shadowing(d2d_handle* h, int32_t n_dev, const double* a_tx_db, const double* a_rx_db,
+                                const double* exponent, double d0_m, double chi_db, uint64_t seed);
+
 /* PathLoss plugin, table route for arbitrary Python subclasses (path_loss.py:12-25;
  * examples/custom_path_loss.py:8-16): pl_db[(e,) tx_dev, rx_dev] evaluated on the host once per
  * episode.  per_env = 0: one [D,D] table shared by all envs; 1: [B,D,D].                           */

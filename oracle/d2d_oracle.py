@@ -203,7 +203,28 @@ def pwr_levels_for(link_type, *, due_min=0, due_max=20, cue_max=23, mbs_max=46):
 
 
 # --------------------------------------------------------------------------- the step
-def step(pos, link_tx, link_rx, rb, pwr, cols: DeviceColumns, spec: PathLossSpec, chunk: int = 64):
+@dataclass
+class ShadowSpec:
+    """ShadowingPathLoss (path_loss.py:69-81) with the draws of csrc/d2d_step.hip: beyond d0 every path-loss
+    evaluation adds chi_db * z, z = Box-Muller of Philox4x32-10(counter = (first_env + b, step, j | i << 16, kind),
+    key = seed); kind 0 = the SINR's signal / interferer terms, kind 1 = the SNR's re-evaluation (simulator.py:114)."""
+    d0_m: float = 100.0
+    chi_db: float = 2.7
+    seed: int = 0
+    step: int = 0
+    first_env: int = 0
+
+    def normals(self, env, j, i, kind):
+        w = philox4x32_10(np.asarray(env, dtype=np.uint64) + np.uint64(self.first_env), np.uint64(self.step),
+                          np.asarray(j, dtype=np.uint64) | (np.asarray(i, dtype=np.uint64) << np.uint64(16)),
+                          np.uint64(kind), self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+        u1 = ((w[0] >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+        u2 = (w[1] >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+        return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def step(pos, link_tx, link_rx, rb, pwr, cols: DeviceColumns, spec: PathLossSpec, chunk: int = 64,
+         shadow: Optional[ShadowSpec] = None):
     """simulator.py:77-154.  pos [B, D, 2] f64; link_tx/link_rx [N] device indices; rb, pwr [B, N].
 
     Returns dict of float64 [B, N]: sinr_db, snr_db, rate_bps, capacity_mbps.
@@ -225,16 +246,20 @@ def step(pos, link_tx, link_rx, rb, pwr, cols: DeviceColumns, spec: PathLossSpec
             tab = np.asarray(spec.table_db, dtype=np.float64)
             tab = tab[s:e] if tab.ndim == 3 else tab[None]
 
-        def pl_of(bi, j, i):
+        def pl_of(bi, j, i, kind=0):
             """PL from the tx of link j to the rx of link i in env bi (index arrays)."""
             if tab is not None:
                 return tab[bi if tab.shape[0] > 1 else 0, link_tx[j], link_rx[i]]
             t = p[bi, link_tx[j]]; r = p[bi, link_rx[i]]
             dist = ((t[..., 0] - r[..., 0]) ** 2 + (t[..., 1] - r[..., 1]) ** 2) ** 0.5   # position.py:11-12
-            return path_loss_db(spec, dist, h_tx[j], h_rx[i])
+            pl = path_loss_db(spec, dist, h_tx[j], h_rx[i])
+            if shadow is not None:                                              # path_loss.py:76-79
+                pl = pl + np.where(dist > shadow.d0_m, shadow.chi_db * shadow.normals(bi + s, j, i, kind), 0.0)
+            return pl
 
         bi, ii = np.meshgrid(np.arange(e - s), np.arange(n), indexing='ij')
         sig = eirp - pl_of(bi, ii, ii) + cols.rx_off_db[link_rx][None, :]       # simulator.py:93
+        sig_snr = sig if shadow is None else eirp - pl_of(bi, ii, ii, 1) + cols.rx_off_db[link_rx][None, :]
         # only links that share an RB interfere (simulator.py:95): evaluate exactly those (j -> i) pairs, like
         # the reference's per-RB sets do, and sum them per receiver in ascending j
         same = (rb[s:e, :, None] == rb[s:e, None, :]) & ~eye[None]              # [b, j, i]
@@ -242,7 +267,7 @@ def step(pos, link_tx, link_rx, rb, pwr, cols: DeviceColumns, spec: PathLossSpec
         ix_mw = db_to_linear(eirp[pb, pj] - pl_of(pb, pj, pi))                  # simulator.py:97-101
         sum_ix = np.bincount(pb * n + pi, weights=ix_mw, minlength=(e - s) * n).reshape(e - s, n)
         sinr = sig - linear_to_db(sum_ix + db_to_linear(noise)[None, :])        # simulator.py:106-107
-        snr = sig - noise[None, :]                                              # simulator.py:115
+        snr = sig_snr - noise[None, :]                                          # simulator.py:114-115
         ok = sinr > cols.sens_dbm[link_rx][None, :]                             # simulator.py:123,149
         shannon = np.log2(1 + db_to_linear(sinr))
         out['sinr_db'][s:e] = sinr

@@ -334,6 +334,32 @@ def main():
         return out
     run_episode(gym, 'case12_array_actions', 112, {}, ld, 2, action_fn=array_actions)
 
+    # (13) ShadowingPathLoss: stochastic (a fresh gauss per call, path_loss.py:79), so what is captured is the
+    # per-link DISTRIBUTION of the reference's outputs over many steps with the same positions and actions.
+    from gym_d2d.path_loss import ShadowingPathLoss
+    seed_all(gym, 113)
+    env = gym.make('D2DEnv-v0', env_config={'num_rbs': 6, 'num_cues': 8, 'num_due_pairs': 12,
+                                            'path_loss_model': ShadowingPathLoss})
+    obs = env.reset()
+    round_positions(env)
+    raw = sample_actions(env, list(obs.keys()))
+    reps = 2000
+    sinr = np.empty((reps, len(raw))); snr = np.empty_like(sinr)
+    for k in range(reps):
+        _, _, _, info = env.step(raw)
+        sinr[k] = [info[key]['sinr_db'] for key in raw]
+        snr[k] = [info[key]['snr_db'] for key in raw]
+    rec = record_step(env, {}, None)
+    for f in ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps', 'reward_system_capacity', 'reward_shannon',
+              'reward_cue_sinr_shannon'):
+        rec.pop(f)          # single draws are meaningless as pins
+    rec.update(raw=np.asarray([raw[k] for k in rec['keys']], dtype=np.int64), reps=np.asarray(reps),
+               sinr_mean=sinr.mean(0), sinr_std=sinr.std(0), snr_mean=snr.mean(0), snr_std=snr.std(0),
+               diff_std=(sinr - snr).std(0), sinr_snr_corr=np.array([np.corrcoef(sinr[:, i], snr[:, i])[0, 1]
+                                                                     for i in range(sinr.shape[1])]))
+    save_case('case13_shadowing', dict(env_meta(env, {'kind': 'shadowing', 'ple': 2.0, 'd0_m': 100.0, 'chi_dB': 2.7}),
+                                       seed=113, case='case13_shadowing'), snapshot_devices(env), [rec])
+
     # known-answer values copied as DATA from the reference's own unit tests (file:line in the key)
     kat = {
         'test_path_loss.py:11 pl_constant_dB(2.1,2.0)': 38.892169116561746,

@@ -33,7 +33,55 @@ def pwr_levels(case, link_type):
                               cue_max=m['cue_max_tx_power_dBm'], mbs_max=m['mbs_max_tx_power_dBm'])
 
 
-@pytest.mark.parametrize('name', case_names())
+def shadow_statistics(sample):
+    """per-link mean/std of sinr, snr and std of (sinr - snr) over the first axis of `sample` = (sinr, snr)."""
+    sinr, snr = sample
+    return {'sinr_mean': sinr.mean(0), 'sinr_std': sinr.std(0), 'snr_mean': snr.mean(0), 'snr_std': snr.std(0),
+            'diff_std': (sinr - snr).std(0)}
+
+
+def check_shadow_statistics(got, s, reps_got, slack=1e-9):
+    """Compare per-link moments with the reference's captured ones (case13).  Standard errors: mean ~ std/sqrt(n),
+    std ~ std/sqrt(2n); both samples are finite, bounds are 6 sigma of the combined error."""
+    reps_ref = int(s.reps)
+    for key in ('sinr', 'snr'):
+        sd = np.maximum(getattr(s, f'{key}_std'), 1e-9)
+        se_mean = sd * np.sqrt(1.0 / reps_ref + 1.0 / reps_got)
+        assert (np.abs(got[f'{key}_mean'] - getattr(s, f'{key}_mean')) <= 6 * se_mean + slack).all(), key
+        se_std = sd * np.sqrt(0.5 / reps_ref + 0.5 / reps_got) * 1.5      # x1.5: sums of log-normals are heavy tailed
+        assert (np.abs(got[f'{key}_std'] - getattr(s, f'{key}_std')) <= 6 * se_std + slack).all(), key
+    sd = np.maximum(s.diff_std, 1e-9)
+    assert (np.abs(got['diff_std'] - s.diff_std) <= 6 * 1.5 * sd * np.sqrt(0.5 / reps_ref + 0.5 / reps_got) + slack).all()
+
+
+def test_oracle_shadowing_matches_reference_distribution():
+    """ShadowingPathLoss is stochastic: pin the oracle's draw structure (independent Gaussians for the SINR signal,
+    every interferer, and the SNR re-evaluation; none within d0) through per-link moments."""
+    case = load_case('case13_shadowing')
+    s = case.steps[0]
+    pl = case.meta['path_loss']
+    assert pl['kind'] == 'shadowing'
+    cols = orc.device_columns(case.cfgs, case.is_bs)
+    spec = orc.PathLossSpec('log_distance', case.meta['carrier_freq_GHz'], ple=pl['ple'])
+    reps = 1500
+    sinr = np.empty((reps, len(s.keys))); snr = np.empty_like(sinr)
+    for k in range(reps):
+        sh = orc.ShadowSpec(pl['d0_m'], pl['chi_dB'], seed=99, step=k)
+        out = orc.step(case.pos[None], s.link_tx, s.link_rx, s.rb[None], s.pwr[None], cols, spec, shadow=sh)
+        sinr[k], snr[k] = out['sinr_db'][0], out['snr_db'][0]
+    check_shadow_statistics(shadow_statistics((sinr, snr)), s, reps)
+    # structure: links shorter than d0 (every DUE pair: <= 20 m) have a deterministic SNR
+    d = np.hypot(*(case.pos[s.link_tx] - case.pos[s.link_rx]).T)
+    assert (s.snr_std[d <= pl['d0_m']] < 1e-9).all() and (snr.std(0)[d <= pl['d0_m']] < 1e-9).all()
+    assert (s.snr_std[d > pl['d0_m']] > 2.0).all()
+    # chi = 0 degenerates to plain log-distance
+    det = orc.step(case.pos[None], s.link_tx, s.link_rx, s.rb[None], s.pwr[None], cols, spec)
+    zero = orc.step(case.pos[None], s.link_tx, s.link_rx, s.rb[None], s.pwr[None], cols, spec,
+                    shadow=orc.ShadowSpec(pl['d0_m'], 0.0, seed=1, step=0))
+    assert rel_err(zero['sinr_db'], det['sinr_db']) < TOL
+
+
+@pytest.mark.parametrize('name', [n for n in case_names() if 'shadowing' not in n])
 def test_oracle_matches_reference(name):
     case = load_case(name)
     cols = orc.device_columns(case.cfgs, case.is_bs)
