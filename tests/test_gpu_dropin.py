@@ -1,0 +1,151 @@
+"""Drop-in behaviour of D2DEnv beyond numbers: plugins written against the reference's ABCs, the device-config
+JSON round trip, render(), the example scripts.  `pytest -m gpu`."""
+import json
+import math
+import os
+import random
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _random_actions(env, obs):
+    return {k: env.action_space['due' if k.startswith('due') else 'cue'].sample() for k in obs}
+
+
+def test_python_obs_and_reward_plugins_see_reference_shaped_arguments():
+    """Subclasses of the reference-style ABCs run as Python over dict views of the GPU results (d2d_env.py:27-28:
+    classes, instantiated with no arguments)."""
+    from gym_d2d_amd.envs import D2DEnv
+    from gym_d2d_amd.envs.obs_fn import ObsFunction
+    from gym_d2d_amd.envs.reward_fn import RewardFunction
+    from gym_d2d_amd.spaces import Box
+    seen = {}
+
+    class SinrOnlyObs(ObsFunction):
+        def get_obs_space(self, env_config):
+            return Box(low=-200.0, high=200.0, shape=(2,))
+
+        def get_state(self, actions, state, devices):
+            seen['devices'] = len(devices)
+            out = {}
+            for ids, action in actions.items():
+                assert action.tx.id == ids[0] and action.rx.position.as_tuple() == devices[ids[1]].position.as_tuple()
+                out[':'.join(ids)] = np.array([state['sinrs_db'][ids], state['snrs_db'][ids]])
+            return out
+
+    class MinRateReward(RewardFunction):
+        def __call__(self, actions, state):
+            worst = min(state['rate_bps'].values())
+            assert set(state) >= {'sinrs_db', 'snrs_db', 'rate_bps', 'capacity_mbps'}
+            return {':'.join(ids): worst for ids in actions.keys()}
+
+    cfg = {'num_rbs': 5, 'num_cues': 4, 'num_due_pairs': 6, 'obs_fn': SinrOnlyObs, 'reward_fn': MinRateReward}
+    env = D2DEnv(cfg)
+    assert 'obs_fn' not in cfg and 'reward_fn' not in cfg          # popped from the caller's dict, like the reference
+    obs = env.reset()
+    assert env.observation_space.shape == (2,) and seen['devices'] == 1 + 4 + 12
+    obs, rewards, done, info = env.step(_random_actions(env, obs))
+    for key in obs:
+        assert obs[key][0] == info[key]['sinr_db'] and obs[key][1] == info[key]['snr_db']
+    assert len(set(rewards.values())) == 1 and next(iter(rewards.values())) == min(i['rate_bps'] for i in info.values())
+    env.simulator.handle.close()
+
+
+def test_subclassed_builtin_reward_still_runs_on_the_gpu():
+    """SystemCapacityRewardFunction subclass with a different threshold (how SURVEY 8(c) case 11 is built)."""
+    from gym_d2d_amd.envs import D2DEnv
+    from gym_d2d_amd.envs.reward_fn import SystemCapacityRewardFunction
+
+    class Strict(SystemCapacityRewardFunction):
+        def __init__(self):
+            super().__init__(min_capacity_mbps=1e9)                 # every non-D2D link fails -> -1 whenever shared
+
+    env = D2DEnv({'num_rbs': 1, 'num_cues': 3, 'num_due_pairs': 3, 'reward_fn': Strict})
+    assert env._native_reward
+    obs = env.reset()
+    obs, rewards, *_ = env.step(_random_actions(env, obs))
+    assert set(rewards.values()) == {-1.0}
+    env.simulator.handle.close()
+
+
+def test_device_config_round_trip(tmp_path):
+    """save_device_config -> device_config_file (d2d_env.py:124-134; env_config.py:32-37; simulator.py:65-66)."""
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_rbs': 4, 'num_cues': 5, 'num_due_pairs': 5})
+    obs = env.reset()
+    acts = _random_actions(env, obs)
+    first = env.step(acts)
+    path = tmp_path / 'device_config.json'
+    env.save_device_config(path)
+    saved = json.loads(path.read_text())
+    assert set(saved) == set(env.simulator.devices) and set(saved['cue00']) == {'position', 'config'}
+    saved['due01']['config']['rx_antenna_gain_dBi'] = 6.0           # hand-edit one device, as the README suggests
+    path.write_text(json.dumps(saved))
+    env2 = D2DEnv({'num_rbs': 4, 'num_cues': 5, 'num_due_pairs': 5, 'device_config_file': path})
+    env2.reset()
+    for dev_id, dev in env.simulator.devices.items():
+        assert env2.simulator.devices[dev_id].position == dev.position
+    second = env2.step(acts)
+    for key in acts:
+        a, b = first[3][key]['sinr_db'], second[3][key]['sinr_db']
+        if key == 'due00:due01':
+            assert b == pytest.approx(a + 6.0, abs=1e-4)            # +6 dBi at that receiver, signal only
+        else:
+            assert a == b
+    env.simulator.handle.close(); env2.simulator.handle.close()
+
+
+def test_render_prints_observations(capsys):
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_rbs': 2, 'num_cues': 1, 'num_due_pairs': 1})
+    with pytest.raises(AssertionError):
+        env.render()
+    env.reset()
+    env.render()
+    assert 'cue00:mbs' in capsys.readouterr().out
+    env.simulator.handle.close()
+
+
+def test_host_reset_reproduces_python_random_stream():
+    """random.seed(k) gives the layout the reference would draw (same consumption order: theta then radius; CUEs,
+    then per pair tx and the rx rejection loop - simulator.py:61-75), rounded to float32."""
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_cues': 3, 'num_due_pairs': 3})
+    random.seed(12)
+    env.reset()
+    got = np.array([d.position.as_tuple() for d in env.simulator.devices.values()])
+    random.seed(12)
+
+    def draw(radius):
+        t = 2 * math.pi * random.random()
+        r = radius * math.sqrt(random.random())
+        return r * math.cos(t), r * math.sin(t)
+
+    want = [(0.0, 0.0)] + [draw(500.0) for _ in range(3)]
+    for _ in range(3):
+        # NB the rx anchor is the tx position AS STORED, i.e. already rounded to float32
+        tx = tuple(float(np.float32(v)) for v in draw(500.0))
+        want.append(tx)
+        while True:
+            dx, dy = draw(20.0)
+            x, y = tx[0] + dx, tx[1] + dy
+            if not x * x + y * y > 500.0 ** 2:
+                want.append((x, y))
+                break
+    assert np.array_equal(got, np.array(want, dtype=np.float32).astype(np.float64))
+    env.simulator.handle.close()
+
+
+@pytest.mark.parametrize('script', ['simple_env.py', 'custom_path_loss.py', 'saving_loading_device_config.py', 'vec_env.py'])
+def test_examples_run(script):
+    r = subprocess.run([sys.executable, str(ROOT / 'examples' / script)], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, 'PYTHONPATH': str(ROOT)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip()
