@@ -24,7 +24,8 @@ OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
 (BUF_POS_X, BUF_POS_Y, BUF_ACTIONS, BUF_RB, BUF_PWR, BUF_SINR_DB, BUF_SNR_DB, BUF_RATE_BPS, BUF_CAPACITY,
  BUF_REWARD, BUF_OBS_TABLE, BUF_OBS, BUF_ENV_FLAGS, BUF_COUNT) = range(14)
 FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
-TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK = 0, 1, 2, 3
+(TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK, TUNE_OBS_VARIANT,
+ TUNE_STEP_THREADS) = range(6)
 
 BUFFER_DTYPES = {BUF_ACTIONS: np.int32, BUF_RB: np.int32, BUF_PWR: np.int32, BUF_ENV_FLAGS: np.int32}
 

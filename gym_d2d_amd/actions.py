@@ -1,4 +1,6 @@
-"""Actions of one step (mirrors gym_d2d/actions.py): who transmits to whom, on which RB, at what power."""
+"""Actions of one step (the reference's gym_d2d/actions.py surface): who transmits to whom, on which resource block,
+at what power.  On the GPU the same information is the link table (tx, rx, type) plus the rb / pwr arrays; these
+objects exist for the dict-style single-env API and for Python plugins."""
 from __future__ import annotations
 
 from collections import UserDict
@@ -11,15 +13,16 @@ from .link_type import LinkType
 
 @dataclass(frozen=True)
 class Action:
-    tx: Device
-    rx: Device
-    link_type: LinkType
-    rb: int
-    tx_pwr_dBm: float
+    tx: Device              # transmitting device
+    rx: Device              # receiving device
+    link_type: LinkType     # derived from the transmitter's class (d2d_env.py:80-91)
+    rb: int                 # resource block index; not range-checked, equality is what matters
+    tx_pwr_dBm: float       # transmit power before antenna gains / losses
 
 
 class Actions(UserDict):
-    """{(tx_id, rx_id): Action}, insertion-ordered = agent order, with a lazily built per-RB index."""
+    """{(tx_id, rx_id): Action}; insertion order is the agent order of every output.  Keeps a per-RB index that is
+    built on first use and dropped by clear()."""
 
     def __init__(self, *args, **kwargs) -> None:
         super().__init__(*args, **kwargs)
@@ -30,7 +33,7 @@ class Actions(UserDict):
         self._by_rb = {}
 
     def get_actions_by_rb(self, rb: int) -> Set[Action]:
-        """All actions sharing resource block `rb` (index built on first use, kept until clear())."""
+        """Every action that uses resource block `rb` (possibly empty)."""
         if not self._by_rb:
             for act in self.data.values():
                 self._by_rb.setdefault(act.rb, set()).add(act)

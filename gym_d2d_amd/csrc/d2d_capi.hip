@@ -62,7 +62,7 @@ struct d2d_handle {
     float reward_param = 0.0f;
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
-    int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0;
+    int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
     unsigned long long env_offset = 0;
     double shadow_chi = 0, shadow_d0 = 0;
     unsigned long long shadow_seed = 0, shadow_step = 0;
@@ -178,6 +178,9 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.mask_words = W;
     s.action_mode = action_mode;
     s.p_due = h->cfg.pwr_levels_due; s.p_cue = h->cfg.pwr_levels_cue; s.p_mbs = h->cfg.pwr_levels_mbs;
+    auto magic = [](int P) -> unsigned long long { return P < 512 ? ((1ull << 40) + (unsigned)P - 1) / (unsigned)P : 0ull; };
+    s.m_due = magic(s.p_due); s.m_cue = magic(s.p_cue); s.m_mbs = magic(s.p_mbs);
+    s.threads = h->tune_step_threads;
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
     void* p = nullptr;
@@ -255,6 +258,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         o.xcd_remap = h->tune_xcd && (h->B % 8 == 0);
         o.nontemporal = h->tune_nt;
         o.block = block;
+        o.variant = h->tune_variant;
         o.table = s.table;
         rc = ensure_buffer(h, D2D_BUF_OBS, &p);
         if (rc) return rc;
@@ -349,7 +353,9 @@ int d2d_destroy(d2d_handle* h) {
 int d2d_set_stream(d2d_handle* h, void* hip_stream) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    // NULL is a real stream (the device's legacy default stream, which is what torch's default stream is): work
+    // enqueued there is ordered with the caller's own kernels and copies.  Only the sentinel selects the private one.
+    h->stream = hip_stream == D2D_STREAM_PRIVATE ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return D2D_OK;
 }
 
@@ -463,6 +469,11 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
         case D2D_TUNE_OBS_ROWS_PER_WG: h->tune_rows = value; break;
         case D2D_TUNE_OBS_NONTEMPORAL: h->tune_nt = value ? 1 : 0; break;
         case D2D_TUNE_OBS_XCD_REMAP: h->tune_xcd = value ? 1 : 0; break;
+        case D2D_TUNE_OBS_VARIANT: h->tune_variant = value; break;
+        case D2D_TUNE_STEP_THREADS:
+            if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "threads must be a multiple of 64 in [64,1024]");
+            h->tune_step_threads = value;
+            break;
         case D2D_TUNE_OBS_BLOCK:
             if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "block must be a multiple of 64 in [64,1024]");
             h->tune_block = value;

@@ -19,6 +19,8 @@ struct StepArgs {
     int mask_words;          // ceil(N/64): u64 words per RB membership mask (0 -> all-pairs path)
     int action_mode;         // 0: raw int actions (a // P, a % P)   1: explicit rb / pwr
     int p_due, p_cue, p_mbs; // power levels per link type (d2d_env.py:31-35)
+    unsigned long long m_due, m_cue, m_mbs;   // ceil(2^40 / P) division magics (0 -> use the hardware divide)
+    int threads;             // threads per workgroup (0 -> one per link, rounded up to a wave, max 1024)
     int reward_fn;
     float reward_param;
     int write_table;
@@ -70,6 +72,7 @@ struct ObsArgs {
     int xcd_remap;
     int nontemporal;
     int block;               // threads per workgroup (0 -> 256)
+    int variant;             // 0: T staged in LDS   1: T read straight from global (A/B)
     const float* table;      // [B,N,6]
     float* obs;              // [B,N,6N]
 };

@@ -77,9 +77,47 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     }
 }
 
+// Variant without LDS staging or barrier (float4 rows only): every thread fetches its two source float2 straight
+// from T in global memory (L1 / the XCD's L2 after the first touch) and stores.  Selected by D2D_TUNE_OBS_VARIANT=1;
+// kept for A/B measurement against the staged kernel (tools/tune_obs.py).
+__global__ __launch_bounds__(1024) void obs_expand_direct_kernel(const ObsArgs a) {
+    const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
+    unsigned env, chunk;
+    if (a.xcd_remap) {
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
+        chunk = rest % a.chunks;
+        env = (rest / a.chunks) * 8u + lane8;
+    } else {
+        env = blockIdx.x / a.chunks;
+        chunk = blockIdx.x % a.chunks;
+    }
+    const unsigned row_floats = 6u * N;
+    const float* t_flat = a.table + (size_t)env * row_floats;
+    const unsigned r0 = chunk * a.rows_per_wg;
+    const unsigned r1 = min(r0 + (unsigned)a.rows_per_wg, N);
+    const unsigned q_per_row = a.q_per_row;
+    const unsigned total = (r1 - r0) * q_per_row;
+    float* out = a.obs + ((size_t)env * N + r0) * row_floats;
+#pragma unroll 2
+    for (unsigned idx = tid; idx < total; idx += T) {
+        const unsigned lr = (unsigned)(((unsigned long long)idx * a.q_magic) >> 40);
+        const unsigned q = idx - lr * q_per_row;
+        const unsigned i = r0 + lr;
+        const unsigned f = q * 4u;
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(t_flat + src_col(f, i));
+        const f32x2 hi = *reinterpret_cast<const f32x2*>(t_flat + src_col(f + 2u, i));
+        const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)idx * 4));
+    }
+}
+
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.N * 6 * sizeof(float);
     dim3 grid((unsigned)a.B * (unsigned)a.chunks), block(a.block > 0 ? a.block : 256);
+    if (a.variant == 1 && a.vec == 4) {
+        hipLaunchKernelGGL(obs_expand_direct_kernel, grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
     if (a.vec == 4) {
         if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<4, true>), grid, block, lds, stream, a);
         else hipLaunchKernelGGL((obs_expand_kernel<4, false>), grid, block, lds, stream, a);

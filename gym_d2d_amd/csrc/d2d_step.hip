@@ -152,8 +152,16 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             // d2d_env.py:94-96 with Python floor semantics; NB due_min_tx_power_dBm is not added back
             const int act = a.actions[row + i];
             const int P = type == LINK_SIDELINK ? a.p_due : (type == LINK_UPLINK ? a.p_cue : a.p_mbs);
-            int q = act / P, r = act - q * P;
-            if (r < 0) { r += P; q -= 1; }
+            int q, r;
+            if (act >= 0) {
+                // exact for 0 <= act < 2^31 and P < 2^9: q = floor(act * ceil(2^40 / P) / 2^40) (host-computed magic)
+                const unsigned long long M = type == LINK_SIDELINK ? a.m_due : (type == LINK_UPLINK ? a.m_cue : a.m_mbs);
+                q = M ? (int)(((unsigned long long)(unsigned)act * M) >> 40) : act / P;
+                r = act - q * P;
+            } else {
+                q = act / P; r = act - q * P;
+                if (r < 0) { r += P; q -= 1; }
+            }
             rb = q; p = r;
         } else {
             rb = a.rb_in[row + i]; p = a.pwr_in[row + i];
@@ -237,9 +245,14 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float ix = acc * rx_pl;                                    // interferers: no rx gains (simulator.py:100)
         const float noise = a.dev_noise_mw[rxd];
         const float sinr_lin = sig / (ix + noise);
-        const float sinr_db = 10.0f * log10f(sinr_lin);                  // simulator.py:106-107
-        const float snr_db = 10.0f * log10f(sig_snr / noise);            // simulator.py:115
-        const float sh = log1pf(sinr_lin) * 1.44269504088896340736f;     // log2(1 + sinr)
+        // dB = 10 log10 x = 3.0103 log2 x, log2 on the transcendental unit (v_log_f32, 1 ulp): abs error < 6e-6 dB
+        // at 80 dB and < 1e-6 dB near 0 dB, inside the 1e-5 * max(|ref|, 1) bar with an order of magnitude to spare
+        const float sinr_db = 3.01029995663981195f * __builtin_amdgcn_logf(sinr_lin);         // simulator.py:106-107
+        const float snr_db = 3.01029995663981195f * __builtin_amdgcn_logf(sig_snr / noise);   // simulator.py:115
+        // log2(1 + x) without losing small x: log2(u) * x / (u - 1), u = fl(1 + x)
+        const float u1p = 1.0f + sinr_lin, um1 = u1p - 1.0f;
+        const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f
+                                     : __builtin_amdgcn_logf(u1p) * (sinr_lin / um1);
         const bool ok = sinr_db > a.dev_sens_db[rxd];                    // simulator.py:123,149
         const float rate = ok ? sh : 0.0f;
         const float cap = ok ? a.dev_bw_mhz[txd] * sh : 0.0f;            // simulator.py:150-151
@@ -341,7 +354,7 @@ hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStr
 }
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream) {
-    int threads = ((a.N + 63) / 64) * 64;
+    int threads = a.threads > 0 ? a.threads : ((a.N + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
     const size_t lds = step_lds_bytes(a.N, a.R, a.mask_words);

@@ -109,7 +109,16 @@ class VecD2DEnv:
         self._t['env_flags'] = alloc(_native.BUF_ENV_FLAGS, (b,), torch.int32)
         if self.obs_fn.native_mode == _native.OBS_LINEAR:
             self._t['obs'] = alloc(_native.BUF_OBS, (b, n, 6 * n), torch.float32)
-        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self._stream_ptr = None
+        self._follow_torch_stream()
+
+    def _follow_torch_stream(self) -> None:
+        """Run the library's kernels on torch's CURRENT stream (the null stream by default) so they are ordered with
+        the torch ops that produce actions / consume results.  Re-bound only when the caller switches streams."""
+        ptr = torch.cuda.current_stream(self.device).cuda_stream
+        if ptr != self._stream_ptr:
+            self.simulator.handle.set_stream(ptr)
+            self._stream_ptr = ptr
 
     def _view(self) -> SimpleNamespace:
         sim = self.simulator
@@ -133,6 +142,8 @@ class VecD2DEnv:
         if seed is not None:
             self._seed, self._episode = int(seed), 0
         self.num_steps = 0
+        if self.use_torch:
+            self._follow_torch_stream()
         self.simulator.reset_device(self._seed, self._episode)
         self._episode += 1
         n_cue = self.config.num_rbs * self.num_pwr_actions['cue']
@@ -159,6 +170,7 @@ class VecD2DEnv:
         """actions: int [B, num_agents] (torch CUDA tensor, or NumPy).  Returns (obs, rewards[B,N], dones[B], info)."""
         sim = self.simulator
         if self.use_torch:
+            self._follow_torch_stream()
             a = self._t['actions']
             src = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions), device=self.device)
             if tuple(src.shape) != (self.num_envs, self.num_agents):

@@ -103,7 +103,10 @@ int d2d_destroy(d2d_handle* h);
 const char* d2d_last_error(void);
 int d2d_abi_version(void);
 
-/* Run on a caller-supplied hipStream_t (e.g. torch's current stream); NULL -> the handle's own.    */
+/* Run on a caller-supplied hipStream_t (e.g. torch's current stream) so that the library's kernels are
+ * ordered with the caller's own work on that stream.  NULL is the device's default (null) stream - a
+ * valid choice; D2D_STREAM_PRIVATE goes back to the handle's own non-blocking stream (the default).   */
+#define D2D_STREAM_PRIVATE ((void*)(intptr_t)-1)
 int d2d_set_stream(d2d_handle* h, void* hip_stream);
 int d2d_synchronize(d2d_handle* h);
 
@@ -152,7 +155,9 @@ typedef enum d2d_tuning {
     D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* obs rows written per workgroup; 0 = auto (~512 KiB per WG)     */
     D2D_TUNE_OBS_NONTEMPORAL = 1,  /* 1 (default): nontemporal stores for the obs stream             */
     D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
-    D2D_TUNE_OBS_BLOCK = 3         /* threads per obs workgroup; 0 = default (256)                   */
+    D2D_TUNE_OBS_BLOCK = 3,        /* threads per obs workgroup; 0 = auto                            */
+    D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): T staged in LDS; 1: T read from global (A/B)      */
+    D2D_TUNE_STEP_THREADS = 5      /* threads per step workgroup (one env); 0 = auto                 */
 } d2d_tuning;
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
 

@@ -355,6 +355,29 @@ def test_vec_env_episode(native):
     env.close()
 
 
+def test_vec_env_is_stream_ordered_with_torch(native):
+    """The library's kernels run on torch's current stream: actions produced by (slow) torch work queued just before
+    step() must be the ones decoded, and results must be visible to torch ops queued right after - on the default
+    stream and on a side stream."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    env = VecD2DEnv({'num_rbs': 7, 'num_cues': 9, 'num_due_pairs': 11}, num_envs=512)
+    obs = env.reset(seed=3)
+    dev = obs.device
+    for stream in (torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)):
+        with torch.cuda.stream(stream):
+            for k in range(3):
+                torch.cuda._sleep(200_000_000)                          # ~0.1 s of GPU time ahead of the producer
+                act = torch.randint(0, 7 * 21, (512, 20), device=dev, dtype=torch.int32)
+                obs, rew, dones, info = env.step(act)
+                got_rb = info['rb'].clone()                             # consumer queued right behind the step
+                want_cue = act[:, :9] // 24
+                want_due = act[:, 9:] // 21
+                assert torch.equal(got_rb[:, :9], want_cue) and torch.equal(got_rb[:, 9:], want_due), (str(stream), k)
+        stream.synchronize()
+    env.close()
+
+
 def test_vec_env_plugin_swap(native):
     """BASELINE config 4: FreeSpacePathLoss through the plugin route + a custom array ObsFunction + Shannon reward."""
     import torch
