@@ -74,6 +74,7 @@ def main():
     ap.add_argument('--envs', type=int, default=0, help='override envs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the per-step all-gather')
+    ap.add_argument('--with-reset', action='store_true', help='redraw all device positions every 10 steps (device-side reset)')
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
     ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket')
     args = ap.parse_args()
@@ -135,6 +136,8 @@ def main():
 
     def run(k0, k1):
         for k in range(k0, k1):
+            if args.with_reset and k % 10 == 0:          # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
+                h.reset_positions(1234, k // 10)
             h.step(actions[k].data_ptr())
             if gatherer is not None:
                 gatherer.launch(env._t['reward'], env._t['table'])
@@ -198,7 +201,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': w['name'], 'envs_per_gpu': b, 'links_per_env': n, 'obs_mode': args.obs,
-                       'reward_fn': 'SystemCapacity', 'path_loss': 'LogDistance(ple=2)', 'positions': 'fixed over the run',
+                       'reward_fn': 'SystemCapacity', 'path_loss': 'LogDistance(ple=2)',
+                       'positions': 'redrawn on the device every 10 steps' if args.with_reset else 'fixed over the run',
                        'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
                        'parallelism': f'env-shard x{world}' + (' + all-gather(reward, obs table)' if gatherer else '')},
             'roofline': roof,

@@ -64,13 +64,13 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
         const unsigned i = r0 + lr;
         const unsigned f = q * VEC;
         if (VEC == 4) {
-            const f32x2 lo = *reinterpret_cast<const f32x2*>(t_flat + src_col(f, i));
-            const f32x2 hi = *reinterpret_cast<const f32x2*>(t_flat + src_col(f + 2u, i));
+            const f32x2 lo = reinterpret_cast<const f32x2*>(t_flat)[src_col(f, i) >> 1];      // even index: one ds_read_b64
+            const f32x2 hi = reinterpret_cast<const f32x2*>(t_flat)[src_col(f + 2u, i) >> 1];
             const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
             f32x4* p = reinterpret_cast<f32x4*>(out + (size_t)idx * 4);
             if (NT) __builtin_nontemporal_store(v, p); else *p = v;
         } else {
-            const f32x2 v = *reinterpret_cast<const f32x2*>(t_flat + src_col(f, i));
+            const f32x2 v = reinterpret_cast<const f32x2*>(t_flat)[src_col(f, i) >> 1];      // even index: one ds_read_b64
             f32x2* p = reinterpret_cast<f32x2*>(out + (size_t)idx * 2);
             if (NT) __builtin_nontemporal_store(v, p); else *p = v;
         }
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(1024) void obs_expand_direct_kernel(const ObsArgs a
         const unsigned q = idx - lr * q_per_row;
         const unsigned i = r0 + lr;
         const unsigned f = q * 4u;
-        const f32x2 lo = *reinterpret_cast<const f32x2*>(t_flat + src_col(f, i));
-        const f32x2 hi = *reinterpret_cast<const f32x2*>(t_flat + src_col(f + 2u, i));
+        const f32x2 lo = reinterpret_cast<const f32x2*>(t_flat)[src_col(f, i) >> 1];      // global_load_dwordx2, L1/L2
+        const f32x2 hi = reinterpret_cast<const f32x2*>(t_flat)[src_col(f + 2u, i) >> 1];
         const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)idx * 4));
     }
