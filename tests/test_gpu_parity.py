@@ -168,6 +168,62 @@ def test_random_batches_match_oracle(native, shape):
     sim.handle.close()
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 1024, 1024), (2, 8, 1024, 1024), (3, 1, 1, 0), (3, 1, 0, 1), (1, 2000, 3, 3)])
+def test_extreme_shapes(native, shape):
+    """Maximum links per env (2048: 90 KB of LDS staging; with 64 RBs the mask table no longer fits and the kernel
+    takes the all-pairs path, with 8 RBs it fits), single-link envs, far more RBs than links."""
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(native, b, rbs, cues, dues, seed=17)
+    sim.handle.set_obs_mode(native.OBS_TABLE if cues + dues > 512 else native.OBS_LINEAR)
+    sim.step_arrays(raw)
+    assert sim.check_flags() == 0
+    ref = _oracle_batch(sim, pos, raw)
+    for f, buf in (('sinr_db', native.BUF_SINR_DB), ('snr_db', native.BUF_SNR_DB), ('rate_bps', native.BUF_RATE_BPS),
+                   ('capacity_mbps', native.BUF_CAPACITY)):
+        assert rel_err(sim.fetch(buf), ref[f]) <= TOL, (shape, f)
+    assert rel_err(sim.fetch(native.BUF_REWARD)[:, 0], ref['reward']) <= TOL
+    assert rel_err(sim.fetch(native.BUF_OBS_TABLE), ref['table']) <= TOL
+    sim.handle.close()
+
+
+def test_invalid_arguments_are_rejected(native):
+    """C-ABI argument checking: sizes, ranges, call order - errors, never crashes."""
+    from gym_d2d_amd.simulator import Simulator
+    with pytest.raises(native.NativeError, match='max_links'):
+        native.Handle(num_envs=1, num_rbs=4, num_cues=2000, num_due_pairs=2000, pwr_levels_due=21, pwr_levels_cue=24,
+                      pwr_levels_mbs=47)
+    with pytest.raises(native.NativeError):
+        native.Handle(num_envs=0, num_rbs=4, num_cues=2, num_due_pairs=2, pwr_levels_due=21, pwr_levels_cue=24,
+                      pwr_levels_mbs=47)
+    h = native.Handle(num_envs=2, num_rbs=4, num_cues=2, num_due_pairs=2, pwr_levels_due=21, pwr_levels_cue=24,
+                      pwr_levels_mbs=47)
+    with pytest.raises(native.NativeError, match='no actions'):
+        h.step()                                                        # nothing configured yet
+    h.upload(native.BUF_ACTIONS, np.zeros((2, 4), dtype=np.int32))
+    with pytest.raises(native.NativeError, match='d2d_set_links'):
+        h.step()
+    with pytest.raises(native.NativeError, match='device index'):
+        h.set_links([1, 99], [0, 0], [1, 1])
+    with pytest.raises(native.NativeError, match='link_type'):
+        h.set_links([1], [0], [7])
+    with pytest.raises(native.NativeError, match='n_dev'):
+        h.set_device_table(*[np.zeros(3)] * 5)
+    h.set_links([1, 3], [0, 4], [1, 3])
+    with pytest.raises(native.NativeError, match='positions'):
+        h.upload(native.BUF_ACTIONS, np.zeros((2, 2), dtype=np.int32)); h.step()
+    with pytest.raises(ValueError):
+        h.set_positions(np.zeros((2, 3)), np.zeros((2, 3)))            # D is 7
+    h.close()
+    sim = Simulator({'num_cues': 2, 'num_due_pairs': 2, 'num_envs': 3})
+    with pytest.raises(ValueError, match='single-env'):
+        from gym_d2d_amd.actions import Actions
+        sim.step(Actions())
+    sim.set_links(sim.default_link_keys())
+    with pytest.raises(ValueError, match=r'\[3,4\]'):
+        sim.step_arrays(np.zeros((3, 5), dtype=np.int32))
+    sim.handle.close()
+
+
 def test_bucketed_and_all_pairs_paths_are_bit_identical(native):
     """Same ascending-index fmaf chain in both interference loops -> identical bits, for every reward function."""
     sim, pos, raw = _batch(native, 32, 16, 40, 60, seed=5)
