@@ -411,6 +411,27 @@ def test_vec_env_episode(native):
     env.close()
 
 
+def test_vec_env_traffic_mode_matches_reference_traffic_model(native):
+    """VecD2DEnv(cue_actions='traffic'): CUE rb/pwr from UplinkTrafficModel, agents act for DUEs only - against the
+    reference's own UplinkTrafficModel.get_traffic fed through its Simulator.step (golden case14)."""
+    from gym_d2d_amd.envs import VecD2DEnv
+    case = load_case('case14_traffic_model')
+    m = case.meta
+    env = VecD2DEnv({'num_rbs': m['num_rbs'], 'num_cues': m['num_cues'], 'num_due_pairs': m['num_due_pairs']},
+                    num_envs=1, cue_actions='traffic', use_torch=False)
+    env.reset(seed=0)
+    env.simulator.set_positions(case.pos[None].astype(np.float32))
+    for s in case.steps:
+        obs, rew, dones, info = env.step(s.due_raw[None].astype(np.int32))
+        assert [f'{t}:{r}' for t, r in env.simulator.link_keys] == s.keys
+        assert (info['rb'][0] == s.rb).all() and (info['tx_pwr_dbm'][0] == s.pwr).all()
+        for f in ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps'):
+            assert rel_err(info[f][0], getattr(s, f)) <= TOL, f
+        assert rel_err(rew[0], s.reward_system_capacity) <= TOL
+        assert rel_err(obs[0][s.obs_rows], s.obs) <= TOL
+    env.close()
+
+
 def test_vec_env_is_stream_ordered_with_torch(native):
     """The library's kernels run on torch's current stream: actions produced by (slow) torch work queued just before
     step() must be the ones decoded, and results must be visible to torch ops queued right after - on the default
