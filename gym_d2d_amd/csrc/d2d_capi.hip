@@ -47,7 +47,7 @@ struct d2d_handle {
     hipStream_t stream = nullptr;
     Buffer buf[D2D_BUF_COUNT];
     // device-side tables
-    float* dev_cols = nullptr;      // 7 columns x D
+    float* dev_cols = nullptr;      // per-link constants, 7 arrays x Nmax (see refresh_tables)
     int* link_tab = nullptr;        // 3 x Nmax
     float* pow10_tab = nullptr;     // 128
     float* gain_table = nullptr;
@@ -56,6 +56,7 @@ struct d2d_handle {
     unsigned* status = nullptr;
     // host-side copies used to derive the device columns
     std::vector<double> eirp_off, rx_off, noise, sens, bw, a_tx, a_rx, expo;
+    std::vector<int> host_tx, host_rx;   // host copy of the link table
     bool have_dev = false, have_pl = false, have_links = false, have_pos = false, tables_dirty = true;
     d2d::PlMode mode = d2d::PL_INV_SQUARE;
     int reward_fn = D2D_REWARD_SYSTEM_CAPACITY;
@@ -124,8 +125,22 @@ int refresh_tables(d2d_handle* h) {
         if (h->mode != d2d::PL_TABLE && h->expo[d] != 2.0) all_two = false;
     }
     if (h->mode != d2d::PL_TABLE && h->mode != d2d::PL_SHADOW) h->mode = all_two ? d2d::PL_INV_SQUARE : d2d::PL_POWER;
-    HIP_TRY(hipMemcpyAsync(h->dev_cols, cols.data(), cols.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));   // cols is a stack-lifetime host buffer
+    // flatten to per-link arrays [7][Nmax]: tx-side columns by the link's tx device, rx-side by its rx device, so
+    // the kernel reads them coalesced by link index with no link -> device -> column double hop
+    const int N = h->N, S = h->Nmax;
+    std::vector<float> lk((size_t)7 * S, 0.0f);
+    for (int i = 0; i < N; ++i) {
+        const int t = h->host_tx[i], r = h->host_rx[i];
+        lk[0 * S + i] = cols[0 * D + t];    // tx_lin
+        lk[1 * S + i] = cols[1 * D + r];    // rx_pl
+        lk[2 * S + i] = cols[2 * D + r];    // rx_lin
+        lk[3 * S + i] = cols[3 * D + r];    // noise_mw
+        lk[4 * S + i] = cols[4 * D + r];    // sens_db
+        lk[5 * S + i] = cols[5 * D + t];    // bw_mhz
+        lk[6 * S + i] = cols[6 * D + t];    // exponent
+    }
+    HIP_TRY(hipMemcpyAsync(h->dev_cols, lk.data(), lk.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // lk is a stack-lifetime host buffer
     h->tables_dirty = false;
     return D2D_OK;
 }
@@ -208,9 +223,10 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     if (s.reward_fn != D2D_REWARD_NONE) GET(D2D_BUF_REWARD, reward, float*);
     if (s.write_table) GET(D2D_BUF_OBS_TABLE, table, float*);
     s.link_tx = h->link_tab; s.link_rx = h->link_tab + h->Nmax; s.link_type = h->link_tab + 2 * h->Nmax;
-    s.dev_tx_lin = h->dev_cols; s.dev_rx_pl = h->dev_cols + D; s.dev_rx_lin = h->dev_cols + 2 * D;
-    s.dev_noise_mw = h->dev_cols + 3 * D; s.dev_sens_db = h->dev_cols + 4 * D; s.dev_bw_mhz = h->dev_cols + 5 * D;
-    s.dev_exp = h->dev_cols + 6 * D;
+    const int S = h->Nmax;
+    s.lk_tx_lin = h->dev_cols; s.lk_rx_pl = h->dev_cols + S; s.lk_rx_lin = h->dev_cols + 2 * S;
+    s.lk_noise_mw = h->dev_cols + 3 * S; s.lk_sens_db = h->dev_cols + 4 * S; s.lk_bw_mhz = h->dev_cols + 5 * S;
+    s.lk_exp = h->dev_cols + 6 * S;
     s.pow10_tab = h->pow10_tab;
     s.gain_table = h->gain_table;
     s.table_env_stride = h->table_per_env ? (long long)D * D : 0;
@@ -318,7 +334,7 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    CREATE_TRY(hipMalloc(&h->dev_cols, (size_t)7 * h->D * 4));
+    CREATE_TRY(hipMalloc(&h->dev_cols, (size_t)7 * h->Nmax * 4));
     CREATE_TRY(hipMalloc(&h->link_tab, (size_t)3 * h->Nmax * 4));
     CREATE_TRY(hipMalloc(&h->pow10_tab, 128 * 4));
     CREATE_TRY(hipMalloc(&h->status, 4));
@@ -439,6 +455,9 @@ int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const i
         HIP_TRY(hipMemcpy(h->link_tab + 2 * h->Nmax, link_type, (size_t)n_links * 4, hipMemcpyHostToDevice));
     }
     h->N = n_links;
+    h->host_tx.assign(tx_dev, tx_dev + n_links);
+    h->host_rx.assign(rx_dev, rx_dev + n_links);
+    h->tables_dirty = true;          // per-link constant arrays follow the link table
     h->have_links = true;
     return D2D_OK;
 }

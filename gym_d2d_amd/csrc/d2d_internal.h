@@ -33,14 +33,14 @@ struct StepArgs {
     const int* link_type;    // [N] 1 uplink, 2 downlink, 3 sidelink
     const float* pos_x;      // [B,D]
     const float* pos_y;      // [B,D]
-    // per-device columns [D]
-    const float* dev_tx_lin;   // 10^((eirp_off - a_tx)/10): EIRP offset and the tx side of the path-loss constant
-    const float* dev_rx_pl;    // 10^(-a_rx/10): rx side of the path-loss constant (applies to signal AND interference)
-    const float* dev_rx_lin;   // 10^(rx_off/10): rx antenna/body/cable terms (signal only, simulator.py:93 vs :100)
-    const float* dev_noise_mw; // 10^(thermal_noise_dBm/10)
-    const float* dev_sens_db;  // rx_sensitivity_dBm
-    const float* dev_bw_mhz;   // 1e-6 * rb bandwidth in Hz
-    const float* dev_exp;      // path-loss exponent of the tx device
+    // per-link constants [N], flattened on the host from the per-device columns whenever links or tables change
+    const float* lk_tx_lin;    // 10^((eirp_off - a_tx)/10) of the tx device: EIRP offset + tx side of the path-loss constant
+    const float* lk_rx_pl;     // 10^(-a_rx/10) of the rx device: rx side of the path-loss constant (signal AND interference)
+    const float* lk_rx_lin;    // 10^(rx_off/10): rx antenna/body/cable terms (signal only, simulator.py:93 vs :100)
+    const float* lk_noise_mw;  // 10^(thermal_noise_dBm/10) of the rx device
+    const float* lk_sens_db;   // rx_sensitivity_dBm of the rx device
+    const float* lk_bw_mhz;    // 1e-6 * RB bandwidth (Hz) of the tx device
+    const float* lk_exp;       // path-loss exponent of the tx device
     const float* pow10_tab;    // [128] 10^(p/10) for integer p dBm
     const float* gain_table;   // PL_TABLE: linear gain [D,D] (tx major)
     long long table_env_stride; // 0 or D*D

@@ -101,6 +101,7 @@ struct Smem {
     float* red;     // [32]
     int* flags;     // [4]  0: env flags  1: reward violated
     u64* mask;      // [R*W] per-RB membership, then [W] sidelink membership
+    unsigned* summ; // [R] bit w set <=> mask[rb][w] != 0: lets a receiver skip the empty words of its RB
 };
 
 __device__ __forceinline__ Smem carve(unsigned char* base, int N) {
@@ -121,8 +122,46 @@ __device__ __forceinline__ Smem carve(unsigned char* base, int N) {
 size_t step_lds_bytes(int N, int R, int mask_words) {
     size_t bytes = (size_t)N * 44 + 32 * 4 + 4 * 4;
     bytes = (bytes + 7) & ~(size_t)7;
-    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words) * 8;
+    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words + (size_t)(R + 1) / 2) * 8;   // masks + summaries
     return bytes;
+}
+
+// Everything pass 1 needs about one link, in registers.
+struct LinkIn {
+    int type, txd, rb, p;
+    float txx, txy, rxx, rxy, tx_lin, p10;
+};
+
+__device__ __forceinline__ LinkIn load_link(const StepArgs& a, const float* px, const float* py, size_t row, int i) {
+    LinkIn in;
+    // hop 1: link table, per-link constant, action
+    in.type = a.link_type[i];
+    in.txd = a.link_tx[i];
+    const int rxd = a.link_rx[i];
+    in.tx_lin = a.lk_tx_lin[i];
+    if (a.action_mode == 0) {
+        // d2d_env.py:94-96 with Python floor semantics; NB due_min_tx_power_dBm is not added back
+        const int act = a.actions[row + i];
+        const int P = in.type == LINK_SIDELINK ? a.p_due : (in.type == LINK_UPLINK ? a.p_cue : a.p_mbs);
+        int q, r;
+        if (act >= 0) {
+            // exact for 0 <= act < 2^31 and P < 2^9: q = floor(act * ceil(2^40 / P) / 2^40) (host-computed magic)
+            const unsigned long long M = in.type == LINK_SIDELINK ? a.m_due : (in.type == LINK_UPLINK ? a.m_cue : a.m_mbs);
+            q = M ? (int)(((unsigned long long)(unsigned)act * M) >> 40) : act / P;
+            r = act - q * P;
+        } else {
+            q = act / P; r = act - q * P;
+            if (r < 0) { r += P; q -= 1; }
+        }
+        in.rb = q; in.p = r;
+    } else {
+        in.rb = a.rb_in[row + i]; in.p = a.pwr_in[row + i];
+    }
+    // hop 2: positions of the two devices, 10^(p/10) for the integer power level
+    in.txx = px[in.txd]; in.txy = py[in.txd];
+    in.rxx = px[rxd]; in.rxy = py[rxd];
+    in.p10 = (unsigned)in.p < 128u ? a.pow10_tab[in.p] : exp10f(0.1f * (float)in.p);
+    return in;
 }
 
 template <int MODE>
@@ -134,47 +173,44 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     Smem s = carve(smem_raw, N);
     // carve() aligns the mask region to 8 bytes the same way step_lds_bytes does
     s.mask = reinterpret_cast<u64*>((reinterpret_cast<uintptr_t>(s.flags + 4) + 7) & ~(uintptr_t)7);
+    s.summ = reinterpret_cast<unsigned*>(s.mask + (size_t)R * W + W);
+
+    // ---- prologue: issue this thread's first link's loads BEFORE any LDS work or barrier, so their latency (the
+    // link table / action hop, then the dependent position / 10^(p/10) hop) overlaps pass 0 and the barrier.
+    // Per-link constants are host-flattened arrays (lk_*[N], d2d_capi.hip refresh_tables), so there is no
+    // link -> device -> column double hop in the kernel.
+    const float* px = a.pos_x + (size_t)b * D;
+    const float* py = a.pos_y + (size_t)b * D;
+    LinkIn first;
+    if (tid < N) first = load_link(a, px, py, row, tid);
 
     // ---- pass 0: clear masks and flags
     const bool want_masks = W > 0;
     if (want_masks)
-        for (int k = tid; k < R * W + W; k += T) s.mask[k] = 0ull;
+        for (int k = tid; k < R * W + W + (R + 1) / 2; k += T) s.mask[k] = 0ull;      // masks + summary words
     if (tid < 4) s.flags[tid] = 0;
     __syncthreads();
 
     // ---- pass 1: decode + stage the transmitter side of every link
-    const float* px = a.pos_x + (size_t)b * D;
-    const float* py = a.pos_y + (size_t)b * D;
+    float4 me0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 rx0 = make_float2(0.f, 0.f);
     for (int i = tid; i < N; i += T) {
-        const int type = a.link_type[i], txd = a.link_tx[i], rxd = a.link_rx[i];
-        int rb, p;
-        if (a.action_mode == 0) {
-            // d2d_env.py:94-96 with Python floor semantics; NB due_min_tx_power_dBm is not added back
-            const int act = a.actions[row + i];
-            const int P = type == LINK_SIDELINK ? a.p_due : (type == LINK_UPLINK ? a.p_cue : a.p_mbs);
-            int q, r;
-            if (act >= 0) {
-                // exact for 0 <= act < 2^31 and P < 2^9: q = floor(act * ceil(2^40 / P) / 2^40) (host-computed magic)
-                const unsigned long long M = type == LINK_SIDELINK ? a.m_due : (type == LINK_UPLINK ? a.m_cue : a.m_mbs);
-                q = M ? (int)(((unsigned long long)(unsigned)act * M) >> 40) : act / P;
-                r = act - q * P;
-            } else {
-                q = act / P; r = act - q * P;
-                if (r < 0) { r += P; q -= 1; }
-            }
-            rb = q; p = r;
-        } else {
-            rb = a.rb_in[row + i]; p = a.pwr_in[row + i];
-        }
-        const float p10 = (unsigned)p < 128u ? a.pow10_tab[p] : exp10f(0.1f * (float)p);
-        s.link[i] = make_float4(px[txd], py[txd], p10 * a.dev_tx_lin[txd], __int_as_float(rb));
-        s.rx[i] = make_float2(px[rxd], py[rxd]);
+        const LinkIn in = i == tid ? first : load_link(a, px, py, row, i);
+        const int type = in.type, txd = in.txd;
+        const int rb = in.rb, p = in.p;
+        const float4 tuple = make_float4(in.txx, in.txy, in.p10 * in.tx_lin, __int_as_float(rb));
+        s.link[i] = tuple;
+        s.rx[i] = make_float2(in.rxx, in.rxy);
         s.aux[i] = txd | (type << 24);
-        if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = a.dev_exp[txd];
+        if (i == tid) { me0 = tuple; rx0 = make_float2(in.rxx, in.rxy); }   // own link stays in registers for pass 2
+        if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = a.lk_exp[i];
         if (a.rb_out) { a.rb_out[row + i] = rb; a.pwr_out[row + i] = p; }
         if (want_masks) {
             const u64 bit = 1ull << (i & 63);
-            if ((unsigned)rb < (unsigned)R) atomicOr(&s.mask[(size_t)rb * W + (i >> 6)], bit);
+            if ((unsigned)rb < (unsigned)R) {
+                atomicOr(&s.mask[(size_t)rb * W + (i >> 6)], bit);
+                atomicOr(&s.summ[rb], 1u << (i >> 6));
+            }
             else atomicOr(&s.flags[0], FLAG_RB_OOR);
             if (type == LINK_SIDELINK) atomicOr(&s.mask[(size_t)R * W + (i >> 6)], bit);
         }
@@ -188,17 +224,23 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     float cap_part = 0.0f;
     int my_flags = 0;
     for (int i = tid; i < N; i += T) {
-        const float4 me = s.link[i];
-        const float2 rx = s.rx[i];
+        const float4 me = i == tid ? me0 : s.link[i];
+        const float2 rx = i == tid ? rx0 : s.rx[i];
         const int rb = __float_as_int(me.w);
-        const int txd = s.aux[i] & 0xFFFFFF;
+        const int txd = i == tid ? first.txd : (s.aux[i] & 0xFFFFFF);
         const int rxd = a.link_rx[i];
+        // per-link receiver / transmitter constants: coalesced, issued ahead of the mask walk that hides them
+        const float rx_pl = a.lk_rx_pl[i], rx_lin = a.lk_rx_lin[i], noise = a.lk_noise_mw[i];
+        const float sens = a.lk_sens_db[i], bw_mhz = a.lk_bw_mhz[i];
         float acc = 0.0f;
         bool zero = false;
 
         if (use_masks) {
             const u64* m = s.mask + (size_t)rb * W;
-            for (int w = 0; w < W; ++w) {
+            unsigned live = s.summ[rb];                                   // non-empty words of this RB, ascending
+            while (live) {
+                const int w = __builtin_ctz(live);
+                live &= live - 1;
                 u64 word = m[w];
                 if (w == (i >> 6)) word &= ~(1ull << (i & 63));          // .difference({action}), simulator.py:95
                 while (word) {
@@ -235,15 +277,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
         else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[i] : 2.0f); zero |= d2 == 0.0f; }
-        const float rx_pl = a.dev_rx_pl[rxd];
-        float sig = me.z * g * rx_pl * a.dev_rx_lin[rxd];                // mW at the receiver, with rx gains
+        float sig = me.z * g * rx_pl * rx_lin;                           // mW at the receiver, with rx gains
         float sig_snr = sig;
         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
             sig_snr = sig * shadow_factor(a, genv, i, i, 1u);            // simulator.py:114: a second, independent draw
             sig *= shadow_factor(a, genv, i, i, 0u);                     // simulator.py:93
         }
         const float ix = acc * rx_pl;                                    // interferers: no rx gains (simulator.py:100)
-        const float noise = a.dev_noise_mw[rxd];
         const float sinr_lin = sig / (ix + noise);
         // dB = 10 log10 x = 3.0103 log2 x, log2 on the transcendental unit (v_log_f32, 1 ulp): abs error < 6e-6 dB
         // at 80 dB and < 1e-6 dB near 0 dB, inside the 1e-5 * max(|ref|, 1) bar with an order of magnitude to spare
@@ -253,9 +293,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float u1p = 1.0f + sinr_lin, um1 = u1p - 1.0f;
         const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f
                                      : __builtin_amdgcn_logf(u1p) * (sinr_lin / um1);
-        const bool ok = sinr_db > a.dev_sens_db[rxd];                    // simulator.py:123,149
+        const bool ok = sinr_db > sens;                                  // simulator.py:123,149
         const float rate = ok ? sh : 0.0f;
-        const float cap = ok ? a.dev_bw_mhz[txd] * sh : 0.0f;            // simulator.py:150-151
+        const float cap = ok ? bw_mhz * sh : 0.0f;                       // simulator.py:150-151
 
         a.sinr_db[row + i] = sinr_db;
         a.snr_db[row + i] = snr_db;
@@ -267,7 +307,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             t[1] = rx;
             t[2] = make_float2(sinr_db, snr_db);
         }
-        s.cap[i] = cap; s.sinr[i] = sinr_db; s.sh[i] = sh;
+        // staged only for the reward pass that reads them (reward_fn.py): 1 -> cap; 2 -> own sinr, sh; 3 -> sinr, sh
+        if (a.reward_fn == 1) s.cap[i] = cap;
+        else if (a.reward_fn >= 2) { s.sinr[i] = sinr_db; s.sh[i] = sh; }
         cap_part += cap;
         if (zero) my_flags |= FLAG_ZERO_DISTANCE;
         if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
@@ -286,7 +328,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             const int rbj = __float_as_int(s.link[j].w);
             bool hit = false;
             if (use_masks) {
-                for (int w = 0; w < W; ++w) hit |= (s.mask[(size_t)rbj * W + w] & s.mask[(size_t)R * W + w]) != 0ull;
+                unsigned live = s.summ[rbj];
+                while (live) {
+                    const int w = __builtin_ctz(live);
+                    live &= live - 1;
+                    hit |= (s.mask[(size_t)rbj * W + w] & s.mask[(size_t)R * W + w]) != 0ull;
+                }
             } else {
                 for (int i = 0; i < N; ++i)
                     hit |= (i != j) & ((s.aux[i] >> 24) == LINK_SIDELINK) & (__float_as_int(s.link[i].w) == rbj);
@@ -310,7 +357,10 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             const int rbi = __float_as_int(s.link[i].w);
             bool bad = false;
             if (use_masks) {
-                for (int w = 0; w < W; ++w) {
+                unsigned live = s.summ[rbi];
+                while (live) {
+                    const int w = __builtin_ctz(live);
+                    live &= live - 1;
                     u64 word = s.mask[(size_t)rbi * W + w] & ~s.mask[(size_t)R * W + w];   // non-sidelink members
                     if (w == (i >> 6)) word &= ~(1ull << (i & 63));
                     while (word) {
