@@ -238,7 +238,6 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         s.shadow_seed_hi = (unsigned)(h->shadow_seed >> 32);
         s.shadow_step = (unsigned)h->shadow_step++;
     }
-    s.status = h->status;
 
     EventPair* ep = nullptr;
     rc = record_start(h, 0, &ep);

@@ -58,8 +58,7 @@ struct StepArgs {
     float* cap;
     float* reward;           // [B,N] (nullable when reward_fn == 0)
     float* table;            // [B,N,6]
-    int* env_flags;          // [B]
-    unsigned* status;        // [1] OR of all env flags
+    int* env_flags;          // [B]  (OR-reduced on demand by launch_flags_or)
 };
 
 struct ObsArgs {

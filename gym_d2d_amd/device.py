@@ -107,9 +107,6 @@ class BaseStation(Device):
     cable_loss_dB = _cfg_property('cable_loss_dB')
     masthead_amplifier_gain_dB = _cfg_property('masthead_amplifier_gain_dB')
 
-    def _feeder_dB(self) -> float:
-        return self.masthead_amplifier_gain_dB - self.cable_loss_dB
-
     def tx_offset_dB(self) -> float:
         return super().tx_offset_dB() - self.cable_loss_dB + self.masthead_amplifier_gain_dB
 

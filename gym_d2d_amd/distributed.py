@@ -12,7 +12,7 @@ Backend "nccl" is RCCL on ROCm; "gloo" works for CPU tensors (used by the CPU te
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.distributed as dist

@@ -23,7 +23,7 @@ from .. import _native
 from ..simulator import Simulator
 from .d2d_env import EPISODE_LENGTH
 from .obs_fn import ArrayObsFunction, LinearObsFunction, ObsFunction
-from .reward_fn import RewardFunction, SystemCapacityRewardFunction
+from .reward_fn import SystemCapacityRewardFunction
 
 try:
     import torch

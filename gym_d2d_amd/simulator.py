@@ -14,7 +14,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _native
-from .actions import Action, Actions
+from .actions import Actions
 from .device import BaseStation, UserEquipment, link_budget_columns
 from .devices import Devices
 from .envs.env_config import EnvConfig
