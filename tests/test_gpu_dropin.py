@@ -102,6 +102,38 @@ def test_device_config_round_trip(tmp_path):
     env.simulator.handle.close(); env2.simulator.handle.close()
 
 
+def test_batched_env_honours_device_config_file(tmp_path):
+    """device_config_file with a batch: pinned devices sit at their file position in EVERY env (simulator.py:65-66),
+    a DUE receiver whose transmitter is pinned is drawn around the pinned position, per-device overrides apply."""
+    from gym_d2d_amd.envs import VecD2DEnv
+    cfg_json = {
+        'cue01': {'position': [100.0, -50.0], 'config': {'num_subcarriers': 12, 'subcarrier_spacing_kHz': 15,
+                                                         'max_tx_power_dBm': 23, 'tx_antenna_gain_dBi': 3.0}},
+        'due02': {'position': [-200.0, 25.0], 'config': {'num_subcarriers': 12, 'subcarrier_spacing_kHz': 15,
+                                                         'max_tx_power_dBm': 20}},
+    }
+    path = tmp_path / 'pinned.json'
+    path.write_text(json.dumps(cfg_json))
+    base = {'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 3}
+    env = VecD2DEnv(dict(base, device_config_file=path), num_envs=64, use_torch=False)
+    ref = VecD2DEnv(dict(base), num_envs=64, use_torch=False)
+    env.reset(seed=9); ref.reset(seed=9)
+    pos, pos_ref = env.simulator.positions(), ref.simulator.positions()
+    idx = env.simulator.devices.index
+    assert (pos[:, idx['cue01']] == np.float32([100.0, -50.0])).all()
+    assert (pos[:, idx['due02']] == np.float32([-200.0, 25.0])).all()
+    d = np.hypot(*(pos[:, idx['due03']] - pos[:, idx['due02']]).T)
+    assert (d <= 20.0 * (1 + 1e-5)).all() and d.std() > 1.0          # around the PINNED tx, still random per env
+    free = [k for name, k in idx.items() if name not in ('cue01', 'due02', 'due03')]
+    assert np.array_equal(pos[:, free], pos_ref[:, free])            # everything else: the same counter-based draws
+    # +3 dBi on cue01's transmit side: its own SNR rises by exactly 3 dB when placed identically
+    ref.simulator.set_positions(pos)
+    acts = np.random.default_rng(0).integers(0, 4 * 21, (64, 6)).astype(np.int32)
+    a = env.step(acts)[3]['snr_db']; b = ref.step(acts)[3]['snr_db']
+    assert np.allclose(a[:, 1] - b[:, 1], 3.0, atol=2e-4) and np.array_equal(a[:, [0, 2, 3, 4, 5]], b[:, [0, 2, 3, 4, 5]])
+    env.close(); ref.close()
+
+
 def test_render_prints_observations(capsys):
     from gym_d2d_amd.envs import D2DEnv
     env = D2DEnv({'num_rbs': 2, 'num_cues': 1, 'num_due_pairs': 1})
