@@ -164,7 +164,11 @@ __device__ __forceinline__ LinkIn load_link(const StepArgs& a, const float* px, 
     return in;
 }
 
-template <int MODE>
+// SINGLE = every thread owns at most one link (N <= blockDim, the normal case up to 1024 links): the per-link loops
+// collapse to a single predicated body, which removes their exec-mask bookkeeping from the scalar pipe.
+#define FOR_MY_LINKS(i) for (int i = tid, go_ = 1; go_ && i < N; i += T, go_ = !SINGLE)
+
+template <int MODE, bool SINGLE>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int N = a.N, R = a.R, D = a.D, W = a.mask_words;
@@ -189,12 +193,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     if (want_masks)
         for (int k = tid; k < R * W + W + (R + 1) / 2; k += T) s.mask[k] = 0ull;      // masks + summary words
     if (tid < 4) s.flags[tid] = 0;
+    if (tid < 32) s.red[tid] = 0.0f;
     __syncthreads();
 
     // ---- pass 1: decode + stage the transmitter side of every link
     float4 me0 = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 rx0 = make_float2(0.f, 0.f);
-    for (int i = tid; i < N; i += T) {
+    FOR_MY_LINKS(i) {
         const LinkIn in = i == tid ? first : load_link(a, px, py, row, i);
         const int type = in.type, txd = in.txd;
         const int rb = in.rb, p = in.p;
@@ -223,7 +228,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // ---- pass 2: interference reduction + SINR/SNR/rate/capacity + obs table
     float cap_part = 0.0f;
     int my_flags = 0;
-    for (int i = tid; i < N; i += T) {
+    bool violated = false;
+    FOR_MY_LINKS(i) {
         const float4 me = i == tid ? me0 : s.link[i];
         const float2 rx = i == tid ? rx0 : s.rx[i];
         const int rb = __float_as_int(me.w);
@@ -308,8 +314,28 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             t[2] = make_float2(sinr_db, snr_db);
         }
         // staged only for the reward pass that reads them (reward_fn.py): 1 -> cap; 2 -> own sinr, sh; 3 -> sinr, sh
-        if (a.reward_fn == 1) s.cap[i] = cap;
-        else if (a.reward_fn >= 2) { s.sinr[i] = sinr_db; s.sh[i] = sh; }
+        if (a.reward_fn >= 2) { s.sinr[i] = sinr_db; s.sh[i] = sh; }    // staged for reward passes 2 / 3 only
+        if (a.reward_fn == 1) {
+            // SystemCapacityRewardFunction's -1 rule (reward_fn.py:29-41), from this link's side: I am a non-D2D
+            // link whose capacity is <= min_capacity and some D2D link shares my RB.  Masks / tuples of ALL links
+            // were published by the barrier before this pass, so no further synchronisation is needed here.
+            const int type_i = i == tid ? first.type : (s.aux[i] >> 24);
+            if (type_i != LINK_SIDELINK && cap <= a.reward_param) {
+                bool hit = false;
+                if (use_masks) {
+                    unsigned live = s.summ[rb];
+                    while (live) {
+                        const int w = __builtin_ctz(live);
+                        live &= live - 1;
+                        hit |= (s.mask[(size_t)rb * W + w] & s.mask[(size_t)R * W + w]) != 0ull;
+                    }
+                } else {
+                    for (int k = 0; k < N; ++k)
+                        hit |= (k != i) & ((s.aux[k] >> 24) == LINK_SIDELINK) & (__float_as_int(s.link[k].w) == rb);
+                }
+                violated |= hit;
+            }
+        }
         cap_part += cap;
         if (zero) my_flags |= FLAG_ZERO_DISTANCE;
         if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
@@ -318,42 +344,26 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 
     // ---- pass 3: reward
     if (a.reward_fn == 1) {
-        // SystemCapacityRewardFunction, reward_fn.py:27-44
+        // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone if any link reported
+        // a violation above.  One barrier: wave partial sums + the violation flag.
         const float wsum = wave_sum(cap_part);
         if ((tid & 63) == 0) s.red[tid >> 6] = wsum;
-        __syncthreads();                                                 // also publishes s.cap
-        for (int j = tid; j < N; j += T) {
-            const int tj = s.aux[j] >> 24;
-            if (tj == LINK_SIDELINK || !(s.cap[j] <= a.reward_param)) continue;
-            const int rbj = __float_as_int(s.link[j].w);
-            bool hit = false;
-            if (use_masks) {
-                unsigned live = s.summ[rbj];
-                while (live) {
-                    const int w = __builtin_ctz(live);
-                    live &= live - 1;
-                    hit |= (s.mask[(size_t)rbj * W + w] & s.mask[(size_t)R * W + w]) != 0ull;
-                }
-            } else {
-                for (int i = 0; i < N; ++i)
-                    hit |= (i != j) & ((s.aux[i] >> 24) == LINK_SIDELINK) & (__float_as_int(s.link[i].w) == rbj);
-            }
-            if (hit) atomicOr(&s.flags[1], 1);
-        }
+        if (violated) atomicOr(&s.flags[1], 1);
         __syncthreads();
         float total = 0.0f;
         const int nw = (T + 63) >> 6;
-        for (int w = 0; w < nw; ++w) total += s.red[w];
+        const float4* red4 = reinterpret_cast<const float4*>(s.red);       // 16 slots, zero-padded: fixed-order sum
+        for (int w = 0; w < (nw + 3) >> 2; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
         const float r = s.flags[1] ? -1.0f : total / (float)N;
-        for (int i = tid; i < N; i += T) a.reward[row + i] = r;
+        FOR_MY_LINKS(i) a.reward[row + i] = r;
     } else if (a.reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57
-        for (int i = tid; i < N; i += T) a.reward[row + i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
+        FOR_MY_LINKS(i) a.reward[row + i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
         __syncthreads();
     } else if (a.reward_fn == 3) {
         // CueSinrShannonRewardFunction, reward_fn.py:65-78
         __syncthreads();
-        for (int i = tid; i < N; i += T) {
+        FOR_MY_LINKS(i) {
             const int rbi = __float_as_int(s.link[i].w);
             bool bad = false;
             if (use_masks) {
@@ -410,15 +420,20 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream) {
     const size_t lds = step_lds_bytes(a.N, a.R, a.mask_words);
     dim3 grid(a.B), block(threads);
     hipError_t err = hipSuccess;
-#define D2D_LAUNCH(M)                                                                                    \
+    const bool single = a.N <= threads;
+#define D2D_LAUNCH_1(M, S)                                                                               \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M>),                    \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M, S>),                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         if (err == hipSuccess) {                                                                         \
-            hipLaunchKernelGGL(step_kernel<M>, grid, block, lds, stream, a);                             \
+            hipLaunchKernelGGL((step_kernel<M, S>), grid, block, lds, stream, a);                        \
             err = hipGetLastError();                                                                     \
         }                                                                                                \
+    } while (0)
+#define D2D_LAUNCH(M)                                                                                    \
+    do {                                                                                                 \
+        if (single) D2D_LAUNCH_1(M, true); else D2D_LAUNCH_1(M, false);                                  \
     } while (0)
     switch (mode) {
         case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;
@@ -427,6 +442,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream) {
         case PL_SHADOW: D2D_LAUNCH(PL_SHADOW); break;
     }
 #undef D2D_LAUNCH
+#undef D2D_LAUNCH_1
     return err;
 }
 
