@@ -455,6 +455,39 @@ def test_vec_env_is_stream_ordered_with_torch(native):
     env.close()
 
 
+def test_step_is_hip_graph_capturable(native):
+    """Steady-state d2d_step allocates nothing and never synchronises, so a caller may capture a rollout into a HIP
+    graph (torch.cuda.graph) and replay it; the replay reproduces the eager results bit for bit."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    env = VecD2DEnv({'num_rbs': 9, 'num_cues': 10, 'num_due_pairs': 14}, num_envs=256)
+    env.reset(seed=2)
+    h, dev = env.simulator.handle, env.device
+    acts = torch.randint(0, 9 * 21, (5, 256, 24), device=dev, dtype=torch.int32)
+    for k in range(5):
+        h.step(acts[k].data_ptr())
+    torch.cuda.synchronize()
+    want = {k: env._t[k].clone() for k in ('sinr_db', 'reward', 'obs')}
+    side = torch.cuda.Stream(device=dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        env._follow_torch_stream()
+        h.step(acts[0].data_ptr())                      # buffers and tables are in place before capture
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for k in range(5):
+                h.step(acts[k].data_ptr())
+    torch.cuda.synchronize()
+    for t in want:
+        env._t[t].zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for t, ref in want.items():
+        assert torch.equal(env._t[t], ref), t
+    env._follow_torch_stream()
+    env.close()
+
+
 def test_vec_env_plugin_swap(native):
     """BASELINE config 4: FreeSpacePathLoss through the plugin route + a custom array ObsFunction + Shannon reward."""
     import torch
