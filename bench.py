@@ -136,9 +136,12 @@ def main():
 
     def run(k0, k1):
         for k in range(k0, k1):
-            if args.with_reset and k % 10 == 0:          # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
+            new_episode = args.with_reset and k % 10 == 0
+            if new_episode:                              # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
                 h.reset_positions(1234, k // 10)
             h.step(actions[k].data_ptr())
+            if gatherer is not None and (new_episode or k == k0):
+                gatherer.gather_positions(env._t['table'])      # position columns only change at reset
             if gatherer is not None:
                 gatherer.launch(env._t['reward'], env._t['table'])
         if gatherer is not None:
@@ -204,7 +207,8 @@ def main():
                        'reward_fn': 'SystemCapacity', 'path_loss': 'LogDistance(ple=2)',
                        'positions': 'redrawn on the device every 10 steps' if args.with_reset else 'fixed over the run',
                        'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
-                       'parallelism': f'env-shard x{world}' + (' + all-gather(reward, obs table)' if gatherer else '')},
+                       'parallelism': f'env-shard x{world}' + (' + per-step all-gather(reward, sinr/snr columns of the obs table; position columns once per episode)'
+                                                                     if gatherer else '')},
             'roofline': roof,
             'kernels': {'step_kernel_ms': step_ms / max(step_n, 1), 'obs_expand_kernel_ms': (obs_ms / obs_n) if obs_n else None},
             'algorithmic_bytes_per_agent_step': core_bytes + (obs_bytes if args.obs == 'linear' else (24.0 if args.obs == 'table' else 0.0)),

@@ -6,8 +6,13 @@ only communication is what a single learner wants to see at the end of a step: o
 is never sent: a consumer re-expands T locally (25.8 GB/GPU over one ~153 GB/s xGMI link per ring hop would take
 seconds per step).
 
-The gather runs on a side stream from a staging copy of T, so it overlaps the obs-expansion kernel and the next
-step; only the 50 MB device-to-device staging copy is ordered against the next step's writes.
+T is further split by how often it changes: its four position columns are constant within an episode
+(simulator.py:61-75 - only reset() moves devices), so they are gathered once per reset (`gather_positions`); the per-step
+gather carries only the (sinr_dB, snr_dB) columns [B_local, N, 2] - a third of the bytes (16.8 MB instead of 50 MB
+per GPU per step at 4096 x 512), which matters because a ring all-gather is bound by ONE xGMI link.
+
+The per-step gather runs on a side stream from a staging copy, so it overlaps the obs-expansion kernel and the next
+step; only the small device-to-device staging copy is ordered against the next step's writes.
 Backend "nccl" is RCCL on ROCm; "gloo" works for CPU tensors (used by the CPU tests).
 """
 from __future__ import annotations
@@ -28,7 +33,14 @@ def shard_range(global_envs: int, world_size: int, rank: int) -> Tuple[int, int]
 
 
 class StepGatherer:
-    """All-gather of (rewards[B_local], table[B_local, N, 6]) across ranks with equal shard sizes."""
+    """All-gather of per-step results across ranks with equal shard sizes.
+
+        g = StepGatherer(b_local, n_links, device)
+        g.gather_positions(table)              # after every reset: the 4 position columns, synchronous
+        g.launch(reward, table)                # after every step: rewards + (sinr, snr), asynchronous
+        rewards, signal = g.wait()             # [B_global], [B_global, N, 2]
+        table = g.table()                      # [B_global, N, 6] assembled on demand
+    """
 
     def __init__(self, b_local: int, n_links: int, device: torch.device, group=None) -> None:
         self.group = group
@@ -38,14 +50,21 @@ class StepGatherer:
         self.cuda = device.type == 'cuda'
         f32 = torch.float32
         self.stage_reward = torch.empty(b_local, dtype=f32, device=device)
-        self.stage_table = torch.empty((b_local, n_links, 6), dtype=f32, device=device)
+        self.stage_signal = torch.empty((b_local, n_links, 2), dtype=f32, device=device)
         self.all_reward = torch.empty(self.world * b_local, dtype=f32, device=device)
-        self.all_table = torch.empty((self.world * b_local, n_links, 6), dtype=f32, device=device)
+        self.all_signal = torch.empty((self.world * b_local, n_links, 2), dtype=f32, device=device)
+        self.all_positions = torch.zeros((self.world * b_local, n_links, 4), dtype=f32, device=device)
         if self.cuda:
             self.comm_stream = torch.cuda.Stream(device=device)
             self.staged = torch.cuda.Event()
             self.done = torch.cuda.Event()
         self._pending = False
+
+    def gather_positions(self, table: torch.Tensor) -> torch.Tensor:
+        """Once per episode: all ranks' (tx_x, tx_y, rx_x, rx_y) columns of T -> [B_global, N, 4]."""
+        local = table[:, :, :4].contiguous()
+        dist.all_gather_into_tensor(self.all_positions, local, group=self.group)
+        return self.all_positions
 
     def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor) -> None:
         """Call right after the step was enqueued on the current stream.  reward_per_agent [B_local, N] (column 0
@@ -55,25 +74,31 @@ class StepGatherer:
             self.comm_stream.wait_stream(cur)                   # results of this step are ready
             with torch.cuda.stream(self.comm_stream):
                 self.stage_reward.copy_(reward_per_agent[:, 0])
-                self.stage_table.copy_(table)
+                self.stage_signal.copy_(table[:, :, 4:6])
                 self.staged.record(self.comm_stream)
                 dist.all_gather_into_tensor(self.all_reward, self.stage_reward, group=self.group)
-                dist.all_gather_into_tensor(self.all_table, self.stage_table, group=self.group)
+                dist.all_gather_into_tensor(self.all_signal, self.stage_signal, group=self.group)
                 self.done.record(self.comm_stream)
             cur.wait_event(self.staged)                         # next step may overwrite table/reward now
         else:
             self.stage_reward.copy_(reward_per_agent[:, 0])
-            self.stage_table.copy_(table)
+            self.stage_signal.copy_(table[:, :, 4:6])
             dist.all_gather_into_tensor(self.all_reward, self.stage_reward, group=self.group)
-            dist.all_gather_into_tensor(self.all_table, self.stage_table, group=self.group)
+            dist.all_gather_into_tensor(self.all_signal, self.stage_signal, group=self.group)
         self._pending = True
 
     def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(rewards [B_global], table [B_global, N, 6]) of the last launched gather, rank-major = env order."""
+        """(rewards [B_global], signal [B_global, N, 2] = sinr_dB, snr_dB) of the last launched gather, rank-major =
+        global env order."""
         if self.cuda and self._pending:
             torch.cuda.current_stream(self.device).wait_event(self.done)
         self._pending = False
-        return self.all_reward, self.all_table
+        return self.all_reward, self.all_signal
+
+    def table(self) -> torch.Tensor:
+        """The global compact obs table [B_global, N, 6] = cached positions ++ latest gathered (sinr, snr)."""
+        _, signal = self.wait()
+        return torch.cat([self.all_positions, signal], dim=2)
 
 
 def expand_table(table: torch.Tensor) -> torch.Tensor:

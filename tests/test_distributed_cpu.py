@@ -49,9 +49,13 @@ def _worker(rank, world, port, global_envs, out_dir):
     begin, end = shard_range(global_envs, world, rank)
     reward, table, obs = _oracle_results(global_envs, begin, end)
     g = StepGatherer(end - begin, table.shape[1], torch.device('cpu'))
+    t_table = torch.from_numpy(table)
+    g.gather_positions(t_table)                          # once per episode: the four position columns
     for _ in range(2):                                   # twice: staging buffers are reusable
-        g.launch(torch.from_numpy(reward), torch.from_numpy(table))
-        all_reward, all_table = g.wait()
+        g.launch(torch.from_numpy(reward), t_table)      # per step: rewards + (sinr, snr) only
+        all_reward, all_signal = g.wait()
+    assert tuple(all_signal.shape) == (global_envs, table.shape[1], 2)
+    all_table = g.table()
     if rank == 0:
         np.save(Path(out_dir) / 'reward.npy', all_reward.numpy())
         np.save(Path(out_dir) / 'table.npy', all_table.numpy())
