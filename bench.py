@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: D2DEnv.step for a batch of environments on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stress|default] [--obs linear|table|none]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stress|default|plugin] [--obs linear|table|none]
 
 A "step" is one pass of the fused path over the whole batch: action decode -> SINR / SNR / rate / capacity -> reward
 -> observation table -> LinearObs expansion (reference semantics: obs materialised as [B, N, 6N] in HBM), with fresh
@@ -9,7 +9,7 @@ i.i.d. actions every step (pre-generated in HBM; positions fixed for the run - t
 devices, simulator.py:61-75).  Metric: agent-steps/s = B * N * steps / wall seconds (whole job, all GPUs).
 
 N > 1: one process per GPU (torch.distributed / RCCL), env axis sharded 4096 per GPU (weak scaling), one all-gather
-per step of rewards + the compact obs table, overlapped on a side stream.
+per step of rewards + the per-step columns of the compact obs table, overlapped on a side stream.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the library's stream) and
 `cpu_baseline` (the NumPy fp64 oracle timed on this box's host cores on a bounded sample; rank 0, N = 1 only).
@@ -32,6 +32,10 @@ WORKLOADS = {
     'stress': dict(name='4096 envs x (256 CUE + 256 DUE pairs, 256 RB), LogDistance', envs=4096, rbs=256, cues=256, dues=256),
     # BASELINE.json configs[1]
     'default': dict(name='1024 envs x (25 CUE + 25 DUE pairs, 25 RB), LogDistance', envs=1024, rbs=25, cues=25, dues=25),
+    # BASELINE.json configs[3]: the plugin-ABI swap - FreeSpacePathLoss class through env_config['path_loss_model'] and
+    # a custom array ObsFunction (own link only); same sizes as 'stress'
+    'plugin': dict(name='4096 envs x (256 CUE + 256 DUE pairs, 256 RB), FreeSpacePathLoss + OwnLinkObsFunction plugins',
+                   envs=4096, rbs=256, cues=256, dues=256, plugin=True),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -104,8 +108,13 @@ def main():
         w['envs'] = args.envs
     b, c, p, r = w['envs'], w['cues'], w['dues'], w['rbs']
     n = c + p
+    if w.get('plugin'):
+        args.obs = 'table'
     cfg = {'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': local,
            'obs_fn': LinearObsFunction if args.obs == 'linear' else OwnLinkObsFunction}
+    if w.get('plugin'):
+        from gym_d2d_amd.path_loss import FreeSpacePathLoss
+        cfg['path_loss_model'] = FreeSpacePathLoss
     env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b)
     h = env.simulator.handle
     if args.obs == 'none':
@@ -204,7 +213,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': w['name'], 'envs_per_gpu': b, 'links_per_env': n, 'obs_mode': args.obs,
-                       'reward_fn': 'SystemCapacity', 'path_loss': 'LogDistance(ple=2)',
+                       'reward_fn': 'SystemCapacity',
+                       'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else 'LogDistance(ple=2)',
                        'positions': 'redrawn on the device every 10 steps' if args.with_reset else 'fixed over the run',
                        'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
                        'parallelism': f'env-shard x{world}' + (' + per-step all-gather(reward, sinr/snr columns of the obs table; position columns once per episode)'
