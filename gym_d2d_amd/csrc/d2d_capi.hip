@@ -270,7 +270,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         if (rows > N) rows = N;
         o.rows_per_wg = rows;
         o.chunks = (N + rows - 1) / rows;
-        o.xcd_remap = h->tune_xcd && (h->B % 8 == 0);
+        o.xcd_remap = (h->tune_xcd > 0 && h->B % (8 * h->tune_xcd) == 0) ? h->tune_xcd : 0;   // envs interleaved per XCD
         o.nontemporal = h->tune_nt;
         o.block = block;
         o.variant = h->tune_variant;
@@ -486,7 +486,7 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
     switch (key) {
         case D2D_TUNE_OBS_ROWS_PER_WG: h->tune_rows = value; break;
         case D2D_TUNE_OBS_NONTEMPORAL: h->tune_nt = value ? 1 : 0; break;
-        case D2D_TUNE_OBS_XCD_REMAP: h->tune_xcd = value ? 1 : 0; break;
+        case D2D_TUNE_OBS_XCD_REMAP: h->tune_xcd = value < 0 ? 0 : value; break;
         case D2D_TUNE_OBS_VARIANT: h->tune_variant = value; break;
         case D2D_TUNE_STEP_THREADS:
             if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "threads must be a multiple of 64 in [64,1024]");

@@ -33,10 +33,12 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
     unsigned env, chunk;
     if (a.xcd_remap) {
-        // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give them the chunks of ONE env
-        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
-        chunk = rest % a.chunks;
-        env = (rest / a.chunks) * 8u + lane8;
+        // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give them the chunks of ONE env (G = 1), or
+        // of G envs interleaved chunk by chunk (G = xcd_remap > 1: more independent write fronts per XCD)
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3, G = (unsigned)a.xcd_remap;
+        const unsigned per_group = a.chunks * G, group = rest / per_group, within = rest % per_group;
+        chunk = within / G;
+        env = (group * G + within % G) * 8u + lane8;
     } else {
         env = blockIdx.x / a.chunks;
         chunk = blockIdx.x % a.chunks;
