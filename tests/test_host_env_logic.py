@@ -1,0 +1,243 @@
+"""CPU-only tests of the env front-ends' HOST logic (key parsing, action decode, link typing, plugin lowering,
+traffic-model actions, error types) with the C-ABI handle replaced by a recording stub.  The stub computes nothing:
+numbers are checked by the -m gpu tests; here only what the host hands to the boundary is."""
+import json
+
+import numpy as np
+import pytest
+
+from gym_d2d_amd import _native
+
+
+class RecordingHandle:
+    """Stands in for _native.Handle: remembers every call, returns zeros for downloads."""
+    instances = []
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.num_envs = kw['num_envs']
+        self.num_devices = 1 + kw['num_cues'] + 2 * kw['num_due_pairs']
+        self.max_links = kw.get('max_links') or (kw['num_cues'] + kw['num_due_pairs'])
+        self.num_links = 0
+        self.calls = []
+        self.uploads = {}
+        RecordingHandle.instances.append(self)
+
+    def _rec(self, name, *args):
+        self.calls.append((name, args))
+
+    def set_device_table(self, *cols): self._rec('device_table', *[np.asarray(c) for c in cols])
+    def set_path_loss_power_law(self, a, b, e): self._rec('power_law', np.asarray(a), np.asarray(b), np.asarray(e))
+    def set_path_loss_shadowing(self, a, b, e, d0, chi, seed): self._rec('shadowing', d0, chi, seed)
+    def set_path_loss_table(self, t): self._rec('table', np.asarray(t))
+    def set_reward(self, rid, param=0.0): self._rec('reward', rid, param)
+    def set_obs_mode(self, m): self._rec('obs_mode', m)
+    def set_env_offset(self, k): self._rec('env_offset', k)
+    def set_stream(self, p): self._rec('stream', p)
+    def reset_positions(self, seed, episode=0, mask=None, xy=None): self._rec('reset', seed, episode, mask, xy)
+    def set_positions(self, x, y, env_begin=0): self._rec('positions', np.asarray(x), np.asarray(y))
+    def status_flags(self): return 0
+    def close(self): self._rec('close')
+
+    def set_links(self, tx, rx, ty):
+        self.num_links = len(tx)
+        self._rec('links', list(tx), list(rx), list(ty))
+
+    def upload(self, which, array, offset_bytes=0):
+        self.uploads[which] = np.array(array)
+
+    def step(self, ptr=0): self._rec('step', ptr)
+    def step_rb_pwr(self, a=0, b=0): self._rec('step_rb_pwr')
+
+    def download(self, which, env_begin=0, env_count=None):
+        b, n, d = (env_count or self.num_envs), self.num_links, self.num_devices
+        shape = {_native.BUF_POS_X: (b, d), _native.BUF_POS_Y: (b, d), _native.BUF_OBS_TABLE: (b, n, 6),
+                 _native.BUF_OBS: (b, n, 6 * n), _native.BUF_ENV_FLAGS: (b,)}.get(which, (b, n))
+        dtype = np.int32 if which in (_native.BUF_RB, _native.BUF_PWR) else np.float32
+        if which in self.uploads and self.uploads[which].shape == shape:
+            return self.uploads[which].astype(dtype)
+        return np.zeros(shape, dtype=dtype)
+
+    def last(self, name):
+        return [args for n, args in self.calls if n == name][-1]
+
+
+@pytest.fixture
+def stub(monkeypatch):
+    RecordingHandle.instances.clear()
+    monkeypatch.setattr(_native, 'Handle', RecordingHandle)
+    return RecordingHandle
+
+
+def test_env_construction_lowers_config_to_tables(stub):
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_rbs': 6, 'num_cues': 3, 'num_due_pairs': 2})
+    h = stub.instances[-1]
+    assert h.kw['pwr_levels_due'] == 21 and h.kw['pwr_levels_cue'] == 24 and h.kw['pwr_levels_mbs'] == 47
+    assert h.kw['max_links'] == 2 * 3 + 2                   # every uplink, downlink and sidelink at once
+    eirp, rxo, noise, sens, bw = h.last('device_table')
+    assert list(eirp) == [15.5] + [-6.0] * 7 and list(rxo) == [17.5] + [-3.0] * 7      # SURVEY 8(a) closed form
+    assert list(noise) == [-118.4] + [-104.5] * 7 and list(bw) == [180000.0] * 8
+    a_tx, a_rx, ple = h.last('power_law')
+    assert a_tx[0] == pytest.approx(38.892169116561746) and (a_rx == 0).all() and (ple == 2.0).all()
+    assert h.last('obs_mode') == (_native.OBS_LINEAR,) and h.last('reward') == (_native.REWARD_SYSTEM_CAPACITY, 0.0)
+    assert env.action_space['due'].n == 6 * 21 and env.action_space['cue'].n == 6 * 24 and env.action_space['mbs'].n == 6 * 47
+    assert env.observation_space.shape == (6 * 5,)
+    assert env.num_steps == 0 and env.actions is None and env.state is None
+
+
+def test_step_parses_keys_types_links_and_decodes(stub):
+    from gym_d2d_amd.envs import D2DEnv
+    from gym_d2d_amd.link_type import LinkType
+    env = D2DEnv({'num_rbs': 6, 'num_cues': 3, 'num_due_pairs': 2})
+    h = stub.instances[-1]
+    raw = {'due02:due03': 5 * 21 + 20, 'cue01:mbs': 2 * 24 + 23, 'mbs:cue00': np.int64(4 * 47 + 46),
+           'due00:due01': np.array([[3], [7]])}
+    obs, rewards, done, info = env.step(raw)
+    # agent order = dict order; device indices follow devices.py:20-25 (mbs, cues, due tx/rx interleaved)
+    assert h.last('links') == ([6, 2, 0, 4], [7, 0, 1, 5], [3, 1, 2, 3])
+    assert h.uploads[_native.BUF_RB].tolist() == [[5, 2, 4, 3]] and h.uploads[_native.BUF_PWR].tolist() == [[20, 23, 46, 7]]
+    assert [a.link_type for a in env.actions.values()] == [LinkType.SIDELINK, LinkType.UPLINK, LinkType.DOWNLINK, LinkType.SIDELINK]
+    assert list(obs) == list(raw) == list(rewards) == list(info) and obs['cue01:mbs'].shape == (24,)
+    assert info['mbs:cue00']['rb'] == 4 and info['mbs:cue00']['tx_pwr_dbm'] == 46 and isinstance(info['mbs:cue00']['rb'], int)
+    assert done == {'__all__': False} and env.num_steps == 1
+    for _ in range(9):
+        _, _, done, _ = env.step(raw)
+    assert done == {'__all__': True}                       # EPISODE_LENGTH = 10 (d2d_env.py:16,68)
+    n_link_uploads = sum(1 for n, _ in h.calls if n == 'links')
+    assert n_link_uploads == 1                             # same link set: the table is not re-sent
+    env.step({'cue01:mbs': 3})
+    assert h.last('links') == ([2], [0], [1])
+
+
+def test_step_error_types_match_reference(stub):
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_cues': 2, 'num_due_pairs': 1})
+    with pytest.raises(ZeroDivisionError):
+        env.step({})                                       # reward_fn.py:42
+    with pytest.raises(TypeError):
+        env.step({'cue00': 1})                             # d2d_env.py:76-77: key must split into exactly two ids
+    with pytest.raises(TypeError):
+        env.step({'a:b:c': 1})
+    with pytest.raises(KeyError):
+        env.step({'cue00:ghost': 1})                       # devices.py:28
+    with pytest.raises(ValueError, match='Unable to decode action type'):
+        env.step({'cue00:mbs': '7'})                       # d2d_env.py:100
+    with pytest.raises(ValueError, match='Unable to decode action type'):
+        env.step({'cue00:mbs': np.array([1, 2])})          # ndarray must have ndim == 2
+    with pytest.raises(TypeError):
+        D2DEnv({'num_cue': 2})                             # unknown config key (dataclass)
+    with pytest.raises(ValueError):
+        D2DEnv({'num_envs': 4})                            # batches go through VecD2DEnv
+
+
+def test_reset_draws_positions_then_steps_with_all_links(stub):
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_cues': 2, 'num_due_pairs': 2, 'cell_radius_m': 100.0, 'd2d_radius_m': 5.0})
+    h = stub.instances[-1]
+    obs = env.reset()
+    assert list(obs) == ['cue00:mbs', 'cue01:mbs', 'due00:due01', 'due02:due03']       # d2d_env.py:54-60
+    x, y = h.last('positions')
+    assert x.shape == (1, 7) and x.dtype == np.float32 and x[0, 0] == 0 and y[0, 0] == 0
+    assert (np.hypot(x, y) <= 100.0 + 1e-3).all()
+    assert np.hypot(x[0, 3] - x[0, 4], y[0, 3] - y[0, 4]) <= 5.0 + 1e-3
+    devs = list(env.simulator.devices.values())
+    assert [d.position.x for d in devs] == [float(v) for v in x[0]]        # objects hold what the GPU holds
+    rb, pw = h.uploads[_native.BUF_RB][0], h.uploads[_native.BUF_PWR][0]
+    assert (rb >= 0).all() and (rb < 25).all() and (pw[:2] <= 23).all() and (pw[2:] <= 20).all()
+
+
+def test_plugin_lowering_choices(stub):
+    from gym_d2d_amd.envs import D2DEnv
+    from gym_d2d_amd.envs.obs_fn import LinearObsFunction, ObsFunction
+    from gym_d2d_amd.envs.reward_fn import CueSinrShannonRewardFunction, RewardFunction, ShannonRewardFunction
+    from gym_d2d_amd.path_loss import AreaType, CostHataPathLoss, PathLoss, ShadowingPathLoss
+    from gym_d2d_amd.spaces import Box
+
+    D2DEnv({'reward_fn': ShannonRewardFunction})
+    assert stub.instances[-1].last('reward') == (_native.REWARD_SHANNON, -70.0)
+
+    class Cue3(CueSinrShannonRewardFunction):
+        def __init__(self):
+            super().__init__(sinr_threshold_dB=3.0)
+    D2DEnv({'reward_fn': Cue3})
+    assert stub.instances[-1].last('reward') == (_native.REWARD_CUE_SINR_SHANNON, 3.0)
+
+    class PyReward(RewardFunction):
+        def __call__(self, actions, state):
+            return {':'.join(k): 0.0 for k in actions}
+    D2DEnv({'reward_fn': PyReward})
+    assert stub.instances[-1].last('reward') == (_native.REWARD_NONE, 0.0)
+
+    class PyObs(ObsFunction):
+        def get_obs_space(self, cfg):
+            return Box(-1, 1, shape=(1,))
+
+        def get_state(self, actions, state, devices):
+            return {}
+    D2DEnv({'obs_fn': PyObs})
+    assert stub.instances[-1].last('obs_mode') == (_native.OBS_TABLE,)
+
+    class OverriddenLinear(LinearObsFunction):
+        def get_state(self, actions, state, devices):
+            return {}
+    D2DEnv({'obs_fn': OverriddenLinear})
+    assert stub.instances[-1].last('obs_mode') == (_native.OBS_TABLE,)       # overridden -> Python, not the kernel
+
+    D2DEnv({'path_loss_model': CostHataPathLoss})
+    a_tx, a_rx, expo = stub.instances[-1].last('power_law')
+    assert expo[0] != expo[1] and a_rx[0] != a_rx[1]                            # per-device heights: BS 23 m vs UE 1.5 m
+
+    D2DEnv({'path_loss_model': ShadowingPathLoss, 'seed': 11})
+    assert stub.instances[-1].last('shadowing') == (100.0, 2.7, 11)
+
+    class Custom(PathLoss):
+        def __call__(self, tx, rx):
+            return 100.0
+    env = D2DEnv({'path_loss_model': Custom, 'num_cues': 1, 'num_due_pairs': 1})
+    assert not any(n in ('power_law', 'shadowing') for n, _ in stub.instances[-1].calls)
+    env.reset()
+    table, = stub.instances[-1].last('table')
+    assert table.shape == (4, 4) and np.isnan(table[0, 0]) and table[0, 1] == 100.0
+
+
+def test_save_device_config_format(stub, tmp_path):
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_cues': 1, 'num_due_pairs': 1})
+    env.reset()
+    path = tmp_path / 'cfg.json'
+    env.save_device_config(path)
+    data = json.loads(path.read_text())
+    assert list(data) == ['mbs', 'cue00', 'due00', 'due01']
+    assert data['mbs']['position'] == [0, 0] and data['cue00']['config']['max_tx_power_dBm'] == 23
+    assert data['due01']['config']['body_loss_dB'] == 3.0 and len(data['due00']['position']) == 2
+
+
+def test_vec_env_host_side(stub):
+    from gym_d2d_amd.envs import VecD2DEnv
+    env = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 2, 'seed': 5}, num_envs=6, cue_actions='traffic',
+                    use_torch=False, first_env=12)
+    h = stub.instances[-1]
+    assert h.kw['max_links'] == 5 and h.last('env_offset') == (12,)
+    assert h.last('links') == ([1, 2, 3, 4, 6], [0, 0, 0, 5, 7], [1, 1, 1, 3, 3])
+    env.reset()
+    assert h.last('reset')[:2] == (5, 0)
+    env.reset()
+    assert h.last('reset')[:2] == (5, 1)                   # next episode, same seed
+    due = np.arange(12, dtype=np.int32).reshape(6, 2)
+    obs, rew, dones, info = env.step(due)
+    sent = h.uploads[_native.BUF_ACTIONS]
+    # CUE columns from UplinkTrafficModel: rb = i mod R, power 23 -> raw = rb * 24 + 23 (traffic_model.py:15-22)
+    assert sent[:, :3].tolist() == [[0 * 24 + 23, 1 * 24 + 23, 2 * 24 + 23]] * 6 and (sent[:, 3:] == due).all()
+    assert obs.shape == (6, 5, 30) and rew.shape == (6, 5) and dones.shape == (6,) and not dones.any()
+    with pytest.raises(ValueError, match=r'\[6,2\]'):
+        env.step(np.zeros((6, 5), dtype=np.int32))
+    with pytest.raises(ValueError):
+        VecD2DEnv({}, num_envs=2, cue_actions='nope', use_torch=False)
+    from gym_d2d_amd.envs.obs_fn import ObsFunction
+
+    class DictObs(ObsFunction):
+        def get_obs_space(self, cfg): return None
+        def get_state(self, a, s, d): return {}
+    with pytest.raises(TypeError):
+        VecD2DEnv({'obs_fn': DictObs}, num_envs=2, use_torch=False)
