@@ -27,6 +27,10 @@ int fail(int code, const std::string& msg) {
             return fail(D2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
 
+// Every entry point that may touch HIP first makes the handle's GPU current for the calling thread: with one
+// process per GPU this is a no-op, but a caller that juggles several devices must not redirect our launches.
+#define USE_DEVICE(h) HIP_TRY(hipSetDevice((h)->cfg.device_ordinal))
+
 struct Buffer {
     void* ptr = nullptr;
     size_t bytes = 0;     // capacity
@@ -367,6 +371,7 @@ int d2d_destroy(d2d_handle* h) {
 
 int d2d_set_stream(d2d_handle* h, void* hip_stream) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     // NULL is a real stream (the device's legacy default stream, which is what torch's default stream is): work
     // enqueued there is ordered with the caller's own kernels and copies.  Only the sentinel selects the private one.
@@ -376,6 +381,7 @@ int d2d_set_stream(d2d_handle* h, void* hip_stream) {
 
 int d2d_synchronize(d2d_handle* h) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return D2D_OK;
 }
@@ -420,6 +426,7 @@ int d2d_set_path_loss_shadowing(d2d_handle* h, int32_t n_dev, const double* a_tx
 
 int d2d_set_path_loss_table(d2d_handle* h, const float* pl_db, int32_t per_env) {
     if (!h || !pl_db) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
     const size_t elems = (size_t)h->D * h->D * (per_env ? (size_t)h->B : 1);
     std::vector<float> lin(elems);
     for (size_t k = 0; k < elems; ++k) lin[k] = (float)std::pow(10.0, -(double)pl_db[k] / 10.0);
@@ -439,6 +446,7 @@ int d2d_set_path_loss_table(d2d_handle* h, const float* pl_db, int32_t per_env) 
 
 int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const int32_t* rx_dev, const int32_t* link_type) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     if (n_links < 0 || n_links > h->Nmax) return fail(D2D_ERR_INVALID, "n_links must be in [0, max_links]");
     if (n_links > 0 && (!tx_dev || !rx_dev || !link_type)) return fail(D2D_ERR_INVALID, "null argument");
     for (int i = 0; i < n_links; ++i) {
@@ -463,6 +471,7 @@ int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const i
 
 int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     if (reward_fn < D2D_REWARD_NONE || reward_fn > D2D_REWARD_CUE_SINR_SHANNON) return fail(D2D_ERR_INVALID, "unknown reward_fn");
     h->reward_fn = reward_fn; h->reward_param = param;
     return D2D_OK;
@@ -470,6 +479,7 @@ int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param) {
 
 int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     if (obs_mode < D2D_OBS_NONE || obs_mode > D2D_OBS_LINEAR) return fail(D2D_ERR_INVALID, "unknown obs_mode");
     h->obs_mode = obs_mode;
     return D2D_OK;
@@ -477,12 +487,14 @@ int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode) {
 
 int d2d_set_bucketing(d2d_handle* h, int32_t enabled) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     h->bucketing = enabled ? 1 : 0;
     return D2D_OK;
 }
 
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     switch (key) {
         case D2D_TUNE_OBS_ROWS_PER_WG: h->tune_rows = value; break;
         case D2D_TUNE_OBS_NONTEMPORAL: h->tune_nt = value ? 1 : 0; break;
@@ -503,6 +515,7 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
 
 int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes) {
     if (!h || !dev_ptr) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
     if (which == D2D_BUF_OBS && h->N == 0) return fail(D2D_ERR_STATE, "set links before asking for the obs buffer");
     int rc = ensure_buffer(h, which, dev_ptr);
@@ -513,6 +526,7 @@ int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes) 
 
 int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
     Buffer& bf = h->buf[which];
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -525,6 +539,7 @@ int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
 
 int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes, size_t dst_offset) {
     if (!h || !host_src) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
     void* p = nullptr;
     int rc = ensure_buffer(h, which, &p);
@@ -539,6 +554,7 @@ int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes,
 
 int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset) {
     if (!h || !host_dst) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
     const Buffer& bf = h->buf[which];
     if (!bf.ptr) return fail(D2D_ERR_STATE, "buffer has never been written");
@@ -559,12 +575,14 @@ int d2d_set_positions(d2d_handle* h, const float* x, const float* y, int32_t env
 
 int d2d_set_env_offset(d2d_handle* h, uint64_t first_env) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     h->env_offset = first_env;
     return D2D_OK;
 }
 
 int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const uint8_t* fixed_mask, const float* fixed_xy) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     if ((fixed_mask == nullptr) != (fixed_xy == nullptr)) return fail(D2D_ERR_INVALID, "fixed_mask and fixed_xy go together");
     void *px = nullptr, *py = nullptr;
     int rc = ensure_buffer(h, D2D_BUF_POS_X, &px);
@@ -591,12 +609,14 @@ int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const ui
 
 int d2d_step(d2d_handle* h, const int32_t* actions_dev) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     if (!actions_dev && !h->buf[D2D_BUF_ACTIONS].ptr) return fail(D2D_ERR_STATE, "no actions: pass a pointer or fill D2D_BUF_ACTIONS");
     return run_step(h, 0, actions_dev, nullptr);
 }
 
 int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     if ((!rb_dev && !h->buf[D2D_BUF_RB].ptr) || (!pwr_dev && !h->buf[D2D_BUF_PWR].ptr))
         return fail(D2D_ERR_STATE, "no rb/pwr: pass pointers or fill D2D_BUF_RB / D2D_BUF_PWR");
     return run_step(h, 1, rb_dev, pwr_dev);
@@ -604,6 +624,7 @@ int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev
 
 int d2d_status_flags(d2d_handle* h, uint32_t* flags) {
     if (!h || !flags) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
     if (!h->buf[D2D_BUF_ENV_FLAGS].ptr) { *flags = 0; return D2D_OK; }
     HIP_TRY(d2d::launch_flags_or(static_cast<const int*>(h->buf[D2D_BUF_ENV_FLAGS].ptr), h->B, h->status, h->stream));
     HIP_TRY(hipMemcpyAsync(flags, h->status, 4, hipMemcpyDeviceToHost, h->stream));
@@ -613,6 +634,7 @@ int d2d_status_flags(d2d_handle* h, uint32_t* flags) {
 
 int d2d_profile_enable(d2d_handle* h, int32_t enabled) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     int rc = drain_events(h);
     if (rc) return rc;
     h->prof = enabled != 0;
@@ -621,6 +643,7 @@ int d2d_profile_enable(d2d_handle* h, int32_t enabled) {
 
 int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
     if (!h || kernel < 0 || kernel > 1) return fail(D2D_ERR_INVALID, "bad argument");
+    USE_DEVICE(h);
     int rc = drain_events(h);
     if (rc) return rc;
     if (total_ms) *total_ms = h->acc_ms[kernel];
@@ -630,6 +653,7 @@ int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* l
 
 int d2d_profile_reset(d2d_handle* h) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
     int rc = drain_events(h);
     if (rc) return rc;
     h->acc_ms[0] = h->acc_ms[1] = 0; h->launches[0] = h->launches[1] = 0;
@@ -638,6 +662,7 @@ int d2d_profile_reset(d2d_handle* h) {
 
 int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s) {
     if (!h || !gb_per_s || iters < 1 || bytes < 16) return fail(D2D_ERR_INVALID, "bad argument");
+    USE_DEVICE(h);
     float* tmp = nullptr;
     HIP_TRY(hipMalloc(&tmp, bytes));
     hipEvent_t e0, e1;
