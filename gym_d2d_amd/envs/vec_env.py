@@ -20,7 +20,8 @@ from typing import Optional
 import numpy as np
 
 from .. import _native
-from ..simulator import Simulator
+from ..simulator import BASE_STATION_ID, Simulator
+from ..traffic_model import DownlinkTrafficModel
 from .d2d_env import EPISODE_LENGTH
 from .obs_fn import ArrayObsFunction, LinearObsFunction, ObsFunction
 from .reward_fn import SystemCapacityRewardFunction
@@ -62,7 +63,14 @@ class VecD2DEnv:
         self.config = cfg
         self.observation_space = self.obs_fn.get_obs_space(cfg)
         self.num_pwr_actions = cfg.num_pwr_actions
-        sim.set_links(sim.default_link_keys())
+        # CUE links: uplinks cueXX -> mbs (what reset() builds, d2d_env.py:54-60), unless the CUEs are driven by a
+        # DownlinkTrafficModel, whose links are mbs -> cueXX (traffic_model.py:25-32)
+        self._cue_kind = 'cue'
+        if cue_actions == 'traffic' and isinstance(sim.traffic_model, DownlinkTrafficModel):
+            self._cue_kind = 'mbs'
+            sim.set_links([(BASE_STATION_ID, c) for c in sim.devices.cues.keys()] + list(sim.devices.dues.keys()))
+        else:
+            sim.set_links(sim.default_link_keys())
         self.num_cues, self.num_due_pairs = cfg.num_cues, cfg.num_due_pairs
         self.num_links = self.num_cues + self.num_due_pairs
         if cue_actions not in ('agent', 'traffic'):
@@ -83,7 +91,7 @@ class VecD2DEnv:
         self._seed = cfg.seed if cfg.seed is not None else 0
         if cue_actions == 'traffic':
             rb, pwr = sim.traffic_model.assignments(sim.devices)
-            self._cue_raw = (rb.astype(np.int64) * self.num_pwr_actions['cue'] + pwr).astype(np.int32)
+            self._cue_raw = (rb.astype(np.int64) * self.num_pwr_actions[self._cue_kind] + pwr).astype(np.int32)
 
     # ------------------------------------------------------------------ buffers
     def _bind_torch_buffers(self) -> None:
@@ -152,7 +160,9 @@ class VecD2DEnv:
             g = torch.Generator(device=self.device)
             g.manual_seed((self._seed * 1000003 + self._episode) & 0x7FFFFFFFFFFF)
             a = self._t['actions']
-            if self.num_cues:
+            if self.num_cues and self.cue_actions == 'traffic':
+                a[:, :self.num_cues] = self._cue_raw_tensor()           # CUE links always follow the traffic model
+            elif self.num_cues:
                 a[:, :self.num_cues] = torch.randint(0, n_cue, (self.num_envs, self.num_cues), generator=g,
                                                      device=self.device, dtype=torch.int32)
             if self.num_due_pairs:
@@ -161,8 +171,9 @@ class VecD2DEnv:
             self.simulator.handle.step()
         else:
             rng = np.random.default_rng((self._seed, self._episode))
-            a = np.concatenate([rng.integers(0, n_cue, (self.num_envs, self.num_cues), dtype=np.int32),
-                                rng.integers(0, n_due, (self.num_envs, self.num_due_pairs), dtype=np.int32)], axis=1)
+            cue = (np.tile(self._cue_raw, (self.num_envs, 1)) if self.cue_actions == 'traffic'
+                   else rng.integers(0, n_cue, (self.num_envs, self.num_cues), dtype=np.int32))
+            a = np.concatenate([cue, rng.integers(0, n_due, (self.num_envs, self.num_due_pairs), dtype=np.int32)], axis=1)
             self.simulator.step_arrays(a)
         return self._observe(self._view())
 
@@ -176,9 +187,7 @@ class VecD2DEnv:
             if tuple(src.shape) != (self.num_envs, self.num_agents):
                 raise ValueError(f'actions must be [{self.num_envs},{self.num_agents}], got {tuple(src.shape)}')
             if self.cue_actions == 'traffic':
-                if not hasattr(self, '_cue_raw_t'):
-                    self._cue_raw_t = torch.as_tensor(self._cue_raw, device=self.device)
-                a[:, :self.num_cues] = self._cue_raw_t
+                a[:, :self.num_cues] = self._cue_raw_tensor()
                 a[:, self.num_cues:] = src
             elif src.data_ptr() != a.data_ptr():
                 a.copy_(src)
@@ -200,6 +209,11 @@ class VecD2DEnv:
         info = {'rb': view.rb, 'tx_pwr_dbm': view.pwr, 'snr_db': view.snr_db, 'sinr_db': view.sinr_db,
                 'rate_bps': view.rate_bps, 'capacity_mbps': view.capacity_mbps}
         return obs, rewards, dones, info
+
+    def _cue_raw_tensor(self):
+        if not hasattr(self, '_cue_raw_t'):
+            self._cue_raw_t = torch.as_tensor(self._cue_raw, device=self.device)
+        return self._cue_raw_t
 
     def _observe(self, view):
         if isinstance(self.obs_fn, ArrayObsFunction):

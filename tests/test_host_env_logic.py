@@ -232,6 +232,14 @@ def test_vec_env_host_side(stub):
     assert obs.shape == (6, 5, 30) and rew.shape == (6, 5) and dones.shape == (6,) and not dones.any()
     with pytest.raises(ValueError, match=r'\[6,2\]'):
         env.step(np.zeros((6, 5), dtype=np.int32))
+    # DownlinkTrafficModel: the CUE links become mbs -> cueXX with the base station's power alphabet (47 levels)
+    from gym_d2d_amd.traffic_model import DownlinkTrafficModel
+    down = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 2, 'traffic_model': DownlinkTrafficModel},
+                     num_envs=2, cue_actions='traffic', use_torch=False)
+    hd = stub.instances[-1]
+    assert hd.last('links') == ([0, 0, 0, 4, 6], [1, 2, 3, 5, 7], [2, 2, 2, 3, 3])
+    down.reset(seed=1)
+    assert hd.uploads[_native.BUF_ACTIONS][:, :3].tolist() == [[0 * 47 + 23, 1 * 47 + 23, 2 * 47 + 23]] * 2
     with pytest.raises(ValueError):
         VecD2DEnv({}, num_envs=2, cue_actions='nope', use_torch=False)
     from gym_d2d_amd.envs.obs_fn import ObsFunction
