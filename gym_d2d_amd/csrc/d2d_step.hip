@@ -100,7 +100,7 @@ struct Smem {
     int* aux;       // [N] tx_dev | link_type << 24
     float* red;     // [32]
     int* flags;     // [4]  0: env flags  1: reward violated
-    u64* mask;      // [R*W] per-RB membership, then [W] sidelink membership
+    u64* mask;      // [W][R] per-RB membership (word-major: lanes with different RBs hit different banks), then [W] sidelink membership
     unsigned* summ; // [R] bit w set <=> mask[rb][w] != 0: lets a receiver skip the empty words of its RB
 };
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (want_masks) {
             const u64 bit = 1ull << (i & 63);
             if ((unsigned)rb < (unsigned)R) {
-                atomicOr(&s.mask[(size_t)rb * W + (i >> 6)], bit);
+                atomicOr(&s.mask[(size_t)(i >> 6) * R + rb], bit);
                 atomicOr(&s.summ[rb], 1u << (i >> 6));
             }
             else atomicOr(&s.flags[0], FLAG_RB_OOR);
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         bool zero = false;
 
         if (use_masks) {
-            const u64* m = s.mask + (size_t)rb * W;
+            const u64* m = s.mask + rb;                                   // word w of this RB: m[w * R]
             unsigned live = s.summ[rb];                                   // non-empty words of this RB, ascending
             while (live) {
                 const int w = __builtin_ctz(live);
                 live &= live - 1;
-                u64 word = m[w];
+                u64 word = m[(size_t)w * R];
                 if (w == (i >> 6)) word &= ~(1ull << (i & 63));          // .difference({action}), simulator.py:95
                 while (word) {
                     const int j = (w << 6) + __builtin_ctzll(word);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     while (live) {
                         const int w = __builtin_ctz(live);
                         live &= live - 1;
-                        hit |= (s.mask[(size_t)rb * W + w] & s.mask[(size_t)R * W + w]) != 0ull;
+                        hit |= (s.mask[(size_t)w * R + rb] & s.mask[(size_t)R * W + w]) != 0ull;
                     }
                 } else {
                     for (int k = 0; k < N; ++k)
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 while (live) {
                     const int w = __builtin_ctz(live);
                     live &= live - 1;
-                    u64 word = s.mask[(size_t)rbi * W + w] & ~s.mask[(size_t)R * W + w];   // non-sidelink members
+                    u64 word = s.mask[(size_t)w * R + rbi] & ~s.mask[(size_t)R * W + w];   // non-sidelink members
                     if (w == (i >> 6)) word &= ~(1ull << (i & 63));
                     while (word) {
                         const int j = (w << 6) + __builtin_ctzll(word);
