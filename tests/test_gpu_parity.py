@@ -355,6 +355,43 @@ def test_shadowing_path_loss(native):
     sim.handle.close()
 
 
+def test_custom_python_path_loss_with_a_batch(native):
+    """The Python-plugin route for B > 1: the user's PathLoss is evaluated per env into a [B, D, D] table
+    (d2d_set_path_loss_table, per_env = 1) after every position change."""
+    import math
+    from gym_d2d_amd.path_loss import PathLoss
+    from gym_d2d_amd.simulator import Simulator
+
+    class TwoSlope(PathLoss):                      # not a single power law: cannot be lowered, must go through the table
+        def __call__(self, tx, rx):
+            d = tx.position.distance(rx.position)
+            base = 40.0 + 20.0 * math.log10(d)
+            return base if d < 50.0 else base + 15.0 * math.log10(d / 50.0) + 0.5 * (tx.antenna_height_m - rx.antenna_height_m)
+
+    b, cues, dues, rbs = 3, 4, 5, 3
+    rng = np.random.default_rng(8)
+    sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b, path_loss_model=TwoSlope))
+    pos = random_layout(rng, b, cues, dues)
+    sim.set_positions(pos)
+    sim.set_links(sim.default_link_keys())
+    raw = np.concatenate([rng.integers(0, rbs * 24, (b, cues)), rng.integers(0, rbs * 21, (b, dues))], 1).astype(np.int32)
+    sim.step_arrays(raw)
+    assert sim.check_flags() & native.FLAG_ZERO_DISTANCE == 0
+    ids, cfgs, is_bs = orc.device_configs(cues, dues)
+    cols = orc.device_columns(cfgs, is_bs)
+    p64 = pos.astype(np.float64)
+    d = np.hypot(p64[:, :, None, 0] - p64[:, None, :, 0], p64[:, :, None, 1] - p64[:, None, :, 1])
+    with np.errstate(divide='ignore'):
+        base = 40.0 + 20.0 * np.log10(d)
+        table = np.where(d < 50.0, base, base + 15.0 * np.log10(d / 50.0) +
+                         0.5 * (cols.ant_h_m[None, :, None] - cols.ant_h_m[None, None, :]))
+    tx, rx, ty = default_links(cues, dues)
+    ref = orc.full_step(p64, tx, rx, ty, raw, cols, orc.PathLossSpec('table', 2.1, table_db=table), with_obs=False)
+    for f, buf in (('sinr_db', native.BUF_SINR_DB), ('snr_db', native.BUF_SNR_DB), ('capacity_mbps', native.BUF_CAPACITY)):
+        assert rel_err(sim.fetch(buf), ref[f]) <= 2e-5, f      # the table itself is float32: one more rounding than usual
+    sim.handle.close()
+
+
 def test_device_reset_matches_oracle_sampler(native):
     """csrc/d2d_reset.hip against the oracle's sampler fed with the same Philox uniforms + the reference's own
     sampler properties (test_position.py:30-44)."""
