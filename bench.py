@@ -90,6 +90,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when its first communicator is
+    # created, so everything until the result is ready goes to stderr instead
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     use_dist = world > 1 or args.force_dist
@@ -227,7 +232,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)                 # the real stdout is back for the one line that belongs there
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)                            # teardown chatter (RCCL / ROCm) goes to stderr again
     if use_dist:
         dist.destroy_process_group()
 
