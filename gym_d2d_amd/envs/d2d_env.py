@@ -100,6 +100,10 @@ class D2DEnv(Env):
         with config_file.open(mode='w') as fid:
             json.dump(snapshot, fid)
 
+    def close(self) -> None:
+        """Release the GPU-side state (gym.Env.close)."""
+        self.simulator.handle.close()
+
     # ------------------------------------------------------------------ internals
     def _run(self, actions: Actions) -> NativeState:
         state = self.simulator.step(actions)
