@@ -149,9 +149,15 @@ int refresh_tables(d2d_handle* h) {
     return D2D_OK;
 }
 
+int drain_events(d2d_handle* h);
+
 int record_start(d2d_handle* h, int kernel, EventPair** out) {
     *out = nullptr;
     if (!h->prof) return D2D_OK;
+    if (h->events_used >= 8192) {              // long profiled runs: fold what is pending instead of growing the pool
+        int rc = drain_events(h);
+        if (rc) return rc;
+    }
     if (h->events_used == h->events.size()) {
         EventPair ep;
         HIP_TRY(hipEventCreate(&ep.start));
