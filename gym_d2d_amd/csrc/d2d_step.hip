@@ -89,11 +89,10 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
     return exp2f(-0.33219280948873623f * a.shadow_chi * z);                     // 10^(-chi z / 10)
 }
 
-// LDS carve-up.  44 bytes per link + masks.
+// LDS carve-up.  40 bytes per link + masks.
 struct Smem {
     float4* link;   // [N] tx_x, tx_y, effective tx power (mW, incl. tx side of the PL constant), rb bits
     float2* rx;     // [N] rx_x, rx_y
-    float* cap;     // [N] capacity_mbps
     float* sinr;    // [N] sinr_db
     float* sh;      // [N] log2(1 + sinr_lin)
     float* expo;    // [N] path-loss exponent of the tx
@@ -108,8 +107,7 @@ __device__ __forceinline__ Smem carve(unsigned char* base, int N) {
     Smem s;
     s.link = reinterpret_cast<float4*>(base);
     s.rx = reinterpret_cast<float2*>(s.link + N);
-    s.cap = reinterpret_cast<float*>(s.rx + N);
-    s.sinr = s.cap + N;
+    s.sinr = reinterpret_cast<float*>(s.rx + N);
     s.sh = s.sinr + N;
     s.expo = s.sh + N;
     s.aux = reinterpret_cast<int*>(s.expo + N);
@@ -120,7 +118,7 @@ __device__ __forceinline__ Smem carve(unsigned char* base, int N) {
 }
 
 size_t step_lds_bytes(int N, int R, int mask_words) {
-    size_t bytes = (size_t)N * 44 + 32 * 4 + 4 * 4;
+    size_t bytes = (size_t)N * 40 + 32 * 4 + 4 * 4;
     bytes = (bytes + 7) & ~(size_t)7;
     if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words + (size_t)(R + 1) / 2) * 8;   // masks + summaries
     return bytes;
