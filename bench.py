@@ -9,14 +9,21 @@ i.i.d. actions every step (pre-generated in HBM; positions fixed for the run - t
 devices, simulator.py:61-75).  Metric: agent-steps/s = B * N * steps / wall seconds (whole job, all GPUs).
 
 N > 1: one process per GPU (torch.distributed / RCCL), env axis sharded 4096 per GPU (weak scaling), one all-gather
-per step of rewards + the per-step columns of the compact obs table, overlapped on a side stream.
+per step of rewards + the per-step columns of the compact obs table, overlapped on a side stream.  `--gpus N` works
+both ways: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK is already set: this
+process IS a rank) and as a plain `python bench.py --gpus N` - then this process is only a launcher: it starts the N
+rank processes BEFORE anything touches HIP (it never imports torch, never re-execs), waits, and exits non-zero if any
+rank failed.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the library's stream) and
-`cpu_baseline` (the NumPy fp64 oracle timed on this box's host cores on a bounded sample; rank 0, N = 1 only).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the library's stream),
+`cpu_baseline` (the NumPy fp64 oracle timed on this box's host cores on a bounded sample; rank 0, N = 1 only; one
+thread, with the all-core figure beside it) and, for N > 1, `rccl_ranks` + all-reduce / all-gather checksums.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -25,13 +32,13 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 import numpy as np
-import torch
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the target metric is quoted on
     'stress': dict(name='4096 envs x (256 CUE + 256 DUE pairs, 256 RB), LogDistance', envs=4096, rbs=256, cues=256, dues=256),
     # BASELINE.json configs[1]
-    'default': dict(name='1024 envs x (25 CUE + 25 DUE pairs, 25 RB), LogDistance', envs=1024, rbs=25, cues=25, dues=25),
+    'default': dict(name='1024 envs x (25 CUE + 25 DUE pairs, 25 RB), LogDistance, UplinkTrafficModel-driven CUEs',
+                    envs=1024, rbs=25, cues=25, dues=25, traffic=True),
     # BASELINE.json configs[3]: the plugin-ABI swap - FreeSpacePathLoss class through env_config['path_loss_model'] and
     # a custom array ObsFunction (own link only); same sizes as 'stress'
     'plugin': dict(name='4096 envs x (256 CUE + 256 DUE pairs, 256 RB), FreeSpacePathLoss + OwnLinkObsFunction plugins',
@@ -40,35 +47,149 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(w, seconds_budget=20.0):
-    """Time the NumPy fp64 oracle (a port of the reference's algorithm; the Python reference cannot travel to this
-    box) on a bounded sample of the same workload, including the materialised LinearObs."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_chunk(job):
+    """One worker's share of the CPU baseline: `calls` oracle steps of `envs` envs each (module-level: picklable)."""
+    c, p, r, envs, calls, seed = job
+    for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[var] = '1'
     from oracle import d2d_oracle as orc
     sys.path.insert(0, str(ROOT / 'tests'))
     from sim_util import default_links, random_layout
-    rng = np.random.default_rng(1234)
-    c, p, r = w['cues'], w['dues'], w['rbs']
-    n = c + p
+    rng = np.random.default_rng(seed)
     ids, cfgs, is_bs = orc.device_configs(c, p)
     cols = orc.device_columns(cfgs, is_bs)
     tx, rx, ty = default_links(c, p)
-    envs_per_call = 16 if n > 100 else 256
-    pos = random_layout(rng, envs_per_call, c, p).astype(np.float64)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        raw = np.concatenate([rng.integers(0, r * 24, (envs_per_call, c)), rng.integers(0, r * 21, (envs_per_call, p))], 1)
-        orc.full_step(pos, tx, rx, ty, raw, cols, orc.PathLossSpec(), with_obs=True, chunk=16)
-        done += envs_per_call
-        dt = time.perf_counter() - t0
-        if dt > seconds_budget * 0.5 or done >= 4096:
-            break
-    return {'value': done * n / dt, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{done} env-steps of the same workload ({done * n} agent-steps, obs materialised), '
-                      f'NumPy fp64 oracle, single thread, {dt:.1f} s; host has {os.cpu_count()} cores',
-            'reference_pure_python_1core_build_container': 6.3e3 if n > 100 else 3.3e4}
+    pos = random_layout(rng, envs, c, p).astype(np.float64)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        raw = np.concatenate([rng.integers(0, r * 24, (envs, c)), rng.integers(0, r * 21, (envs, p))], 1)
+        orc.full_step(pos, tx, rx, ty, raw, cols, orc.PathLossSpec(), with_obs=True, chunk=envs)
+    return envs * calls, time.perf_counter() - t0
 
 
-def main():
+def cpu_baseline(w, seconds_budget=10.0):
+    """Time the NumPy fp64 oracle (a port of the reference's algorithm; the Python reference cannot travel to this
+    box) on a bounded sample of the same workload, including the materialised LinearObs: one thread (`value`), and a
+    process pool over env chunks on every core this process may run on (`all_cores`).  Runs BEFORE this process
+    initialises HIP, so forking workers is safe."""
+    c, p, r = w['cues'], w['dues'], w['rbs']
+    n = c + p
+    envs = 8 if n > 100 else 128
+    # -- one thread: calibrate, then run ~seconds_budget/2
+    done, dt = _cpu_chunk((c, p, r, envs, 1, 1234))
+    calls = max(1, min(512, int(0.5 * seconds_budget / max(dt, 1e-3))))
+    done, dt = _cpu_chunk((c, p, r, envs, calls, 1234))
+    single = done * n / dt
+    out = {'value': single, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{done} env-steps of the same workload ({done * n} agent-steps, obs materialised), '
+                     f'NumPy fp64 oracle, single thread, {dt:.1f} s; host has {os.cpu_count()} cores',
+           'reference_pure_python_1core_build_container': 6.3e3 if n > 100 else 3.3e4}
+    # -- every core: one process per core (NumPy elementwise code holds the GIL; BLAS threads pinned to 1)
+    try:
+        import multiprocessing as mp
+        cores = len(os.sched_getaffinity(0))
+        per_call = dt / calls
+        calls_each = max(1, int(0.4 * seconds_budget / max(per_call, 1e-3)))
+        t0 = time.perf_counter()
+        with mp.get_context('fork').Pool(cores) as pool:
+            res = pool.map(_cpu_chunk, [(c, p, r, envs, calls_each, 1000 + k) for k in range(cores)], chunksize=1)
+        wall = time.perf_counter() - t0
+        total = sum(d for d, _ in res)
+        out['all_cores'] = {'value': total * n / wall, 'unit': 'agent-steps/s', 'cores': cores,
+                            'sample': f'{total} env-steps over {cores} worker processes (one per core, 1 NumPy/BLAS thread '
+                                      f'each, {envs} envs per oracle call), {wall:.1f} s wall incl. pool start'}
+    except Exception as exc:                      # pragma: no cover - a baseline failure must not lose the GPU number
+        out['all_cores'] = {'error': repr(exc)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start one rank process per GPU and wait for them.  This process never touches HIP (torch is not even imported
+    here) and never execs: the ranks are ordinary children.  Rank 0 inherits stdout (the JSON line); the other ranks'
+    stdout goes to stderr.  Returns the exit code (first failing rank's, else 0)."""
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, D2D_BENCH_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env,
+                                      stdout=None if rank == 0 else sys.stderr))
+    code = 0
+    live = set(range(n))
+    while live:
+        for rank in sorted(live):
+            rc = procs[rank].poll()
+            if rc is None:
+                continue
+            live.discard(rank)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                print(f'bench launcher: rank {rank} exited with {rc}; stopping the other ranks', file=sys.stderr)
+                for other in live:
+                    procs[other].terminate()            # exact PIDs of our own children
+        time.sleep(0.05)
+    return code
+
+
+# ------------------------------------------------------------------------------------------------ test stub
+class _StubHandle:
+    """CPU stand-in for the native handle (launcher / gather plumbing test on gloo; never a measurement)."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def step(self, ptr=0):
+        self.env.k += 1
+        self.env._t['reward'].fill_(float(self.env.first_env + self.env.k))
+        self.env._t['table'][:, :, 4:] = float(self.env.k)
+
+    def reset_positions(self, *a):
+        pass
+
+    def profile_reset(self):
+        pass
+
+    def profile_enable(self, on):
+        pass
+
+    def profile_read(self, k):
+        return 0.0, 0
+
+    def set_obs_mode(self, m):
+        pass
+
+
+class _StubEnv:
+    def __init__(self, torch, b, n, first_env):
+        self.k, self.first_env = 0, first_env
+        self._t = {'reward': torch.zeros(b, n), 'table': torch.zeros(b, n, 6)}
+        self._t['table'][:, :, :4] = torch.arange(first_env, first_env + b, dtype=torch.float32)[:, None, None]
+        self.num_pwr_actions = {'cue': 24, 'due': 21, 'mbs': 47}
+        self.simulator = type('S', (), {})()
+        self.simulator.handle = _StubHandle(self)
+
+    def reset(self, seed=None):
+        pass
+
+    def status_flags(self):
+        return 0
+
+    def close(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
@@ -76,77 +197,116 @@ def main():
     ap.add_argument('--workload', default='stress', choices=sorted(WORKLOADS))
     ap.add_argument('--obs', default='linear', choices=['linear', 'table', 'none'])
     ap.add_argument('--envs', type=int, default=0, help='override envs per GPU')
+    ap.add_argument('--cue-actions', default='', choices=['', 'agent', 'traffic'],
+                    help="who drives the CUE links (default: the workload's own choice)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the per-step all-gather')
     ap.add_argument('--with-reset', action='store_true', help='redraw all device positions every 10 steps (device-side reset)')
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
-    ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket')
-    args = ap.parse_args()
+    ap.add_argument('--single-env-latency', action='store_true', help='also time the drop-in D2DEnv.step (host dicts), N = 1 only')
+    ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,variant,fuse')
+    ap.add_argument('--stub-cpu', action='store_true',
+                    help='TEST HOOK: no GPU, gloo backend, synthetic per-rank results - exercises only the launcher / gather plumbing')
+    return ap.parse_args(argv)
 
+
+def worker(args):
+    import torch
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit(f'WORLD_SIZE={world} but --gpus {args.gpus}')
+    if os.environ.get('D2D_BENCH_TEST_FAIL_RANK') == str(rank):       # test hook: a rank that dies must fail the job
+        raise SystemExit(3)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when its first communicator is
-    # created, so everything until the result is ready goes to stderr instead
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-
-    from gym_d2d_amd import _native
-    from gym_d2d_amd.envs import VecD2DEnv
-    from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
-
     w = dict(WORKLOADS[args.workload])
     if args.envs:
         w['envs'] = args.envs
     b, c, p, r = w['envs'], w['cues'], w['dues'], w['rbs']
     n = c + p
+    stub = args.stub_cpu
+
+    # the CPU baseline runs first: this process has not initialised HIP yet, so its fork()ed pool is safe
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not stub:
+        cpu = cpu_baseline(w)
+
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when its first communicator is
+    # created, so everything until the result is ready goes to stderr instead
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if stub:
+        dev = torch.device('cpu')
+    else:
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f'rank {rank}: needs GPU {local} but this box exposes {torch.cuda.device_count()}')
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        if stub:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
     if w.get('plugin'):
         args.obs = 'table'
-    cfg = {'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': local,
-           'obs_fn': LinearObsFunction if args.obs == 'linear' else OwnLinkObsFunction}
-    if w.get('plugin'):
-        from gym_d2d_amd.path_loss import FreeSpacePathLoss
-        cfg['path_loss_model'] = FreeSpacePathLoss
-    env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b)
-    h = env.simulator.handle
-    if args.obs == 'none':
-        h.set_obs_mode(_native.OBS_NONE)
-    for kv in filter(None, args.tune.split(',')):
-        k, v = kv.split('=')
-        if k == 'bucket':
-            h.set_bucketing(bool(int(v)))
-        else:
-            h.set_tuning({'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
-                          'xcd': _native.TUNE_OBS_XCD_REMAP}[k], int(v))
-    env.reset(seed=1234)
+    cue_mode = args.cue_actions or ('traffic' if w.get('traffic') else 'agent')
+    if stub:
+        env = _StubEnv(torch, b, n, rank * b)
+        h = env.simulator.handle
+        n_agents = n
+    else:
+        from gym_d2d_amd import _native
+        from gym_d2d_amd.envs import VecD2DEnv
+        from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
+        cfg = {'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': local,
+               'obs_fn': LinearObsFunction if args.obs == 'linear' else OwnLinkObsFunction}
+        if w.get('plugin'):
+            from gym_d2d_amd.path_loss import FreeSpacePathLoss
+            cfg['path_loss_model'] = FreeSpacePathLoss
+        env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b, cue_actions=cue_mode)
+        h = env.simulator.handle
+        n_agents = env.num_agents
+        if args.obs == 'none':
+            h.set_obs_mode(_native.OBS_NONE)
+        tune_keys = {'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
+                     'xcd': _native.TUNE_OBS_XCD_REMAP, 'block': _native.TUNE_OBS_BLOCK,
+                     'threads': _native.TUNE_STEP_THREADS, 'epw': _native.TUNE_STEP_ENVS_PER_WG,
+                     'sblock': _native.TUNE_STEP_BLOCK, 'variant': _native.TUNE_STEP_VARIANT, 'fuse': _native.TUNE_STEP_FUSE_OBS}
+        for kv in filter(None, args.tune.split(',')):
+            k, v = kv.split('=')
+            if k == 'bucket':
+                h.set_bucketing(bool(int(v)))
+            else:
+                h.set_tuning(tune_keys[k], int(v))
+        env.reset(seed=1234)
 
     total = args.steps + args.warmup
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     pc, pd = env.num_pwr_actions['cue'], env.num_pwr_actions['due']
-    actions = torch.empty((total, b, n), dtype=torch.int32, device=dev)
-    if c:
+    # actions of the links the AGENTS drive: [total, B, C+P], or DUE-only [total, B, P] when the CUEs follow the traffic model
+    actions = torch.empty((total, b, n_agents), dtype=torch.int32, device=dev)
+    if n_agents == n and c:
         actions[:, :, :c] = torch.randint(0, r * pc, (total, b, c), generator=g, device=dev, dtype=torch.int32)
     if p:
-        actions[:, :, c:] = torch.randint(0, r * pd, (total, b, p), generator=g, device=dev, dtype=torch.int32)
+        actions[:, :, n_agents - p:] = torch.randint(0, r * pd, (total, b, p), generator=g, device=dev, dtype=torch.int32)
 
     gatherer = None
     if use_dist and not args.no_gather:
         from gym_d2d_amd.distributed import StepGatherer
         gatherer = StepGatherer(b, n, dev)
+
+    # Per-launch HIP events cost a few microseconds of queue time each: irrelevant beside a 3.7 ms obs kernel, a
+    # third of the step for the small workload.  There the timed region runs WITHOUT them, and the kernel durations
+    # for the roofline block come from a second, instrumented pass over the same steps right after it.
+    events_in_timed = n > 128
 
     def run(k0, k1):
         for k in range(k0, k1):
@@ -162,57 +322,82 @@ def main():
             gatherer.wait()
 
     def fence():
-        torch.cuda.synchronize(dev)
+        if not stub:
+            torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not stub:
+            torch.cuda.synchronize(dev)
 
     run(0, args.warmup)
     fence()
     h.profile_reset()
-    h.profile_enable(True)
+    h.profile_enable(events_in_timed)
     t0 = time.perf_counter()
     run(args.warmup, total)
     fence()
     dt = time.perf_counter() - t0
+    if not events_in_timed and not stub:
+        h.profile_reset(); h.profile_enable(True)
+        run(args.warmup, total)
+        fence()
     step_ms, step_n = h.profile_read(0)
     obs_ms, obs_n = h.profile_read(1)
     h.profile_enable(False)
     flags = env.status_flags()
 
+    dist_info = {}
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # evidence that the collective saw every rank: a count all-reduce, and the last step's rewards summed two ways
+        # (all-reduce of the local sums vs the sum of what the all-gather delivered)
+        ones = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(ones)
+        local_sum = env._t['reward'][:, 0].double().sum().reshape(1)
+        dist.all_reduce(local_sum)
+        dist_info = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
+                     'allreduce_rank_count': float(ones.item()), 'allreduce_reward_checksum': float(local_sum.item())}
+        if gatherer is not None:
+            all_reward, all_signal = gatherer.wait()
+            gsum = float(all_reward.double().sum().item())
+            dist_info['allgather_reward_checksum'] = gsum
+            dist_info['allgather_envs'] = int(all_reward.numel())
+            dist_info['checksums_agree'] = bool(abs(gsum - dist_info['allreduce_reward_checksum'])
+                                                <= 1e-6 * max(1.0, abs(gsum)))
+
+    single_ms = None
+    if rank == 0 and world == 1 and args.single_env_latency and not stub:
+        single_ms = single_env_latency(c, p, r, local)
 
     if rank == 0:
         agent_steps = b * n * args.steps * world
         value = agent_steps / dt
         core_bytes = 40.0                      # action 4 + positions 16 + outputs 16 + reward 4
         obs_bytes = 24.0 * n                   # LinearObs materialised: 6N floats per agent
-        if args.obs == 'linear' and obs_n:
+        fused = args.obs == 'linear' and not obs_n         # small N: the expansion runs inside the step launch
+        if fused:
+            per_launch = b * n * (core_bytes + obs_bytes)
+            avg_ms = step_ms / max(step_n, 1)
+            roof = {'kernel': 'step_kernel (LinearObs expansion fused)'}
+        elif args.obs == 'linear' and obs_n:
             # dominant kernel: obs expansion.  Algorithmic bytes per launch = B*N*(24N written + 24 read of T)
             per_launch = b * n * (obs_bytes + 24.0)
-            avg_s = obs_ms / obs_n * 1e-3
-            roof = {'kernel': 'obs_expand_kernel', 'bound': 'hbm', 'achieved': per_launch / avg_s / 1e9,
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'avg_launch_ms': obs_ms / obs_n,
-                    'algorithmic_bytes_per_launch': per_launch, 'traffic': None}
+            avg_ms = obs_ms / obs_n
+            roof = {'kernel': 'obs_expand_kernel'}
         else:
             per_launch = b * n * (core_bytes + (24.0 if args.obs == 'table' else 0.0))
-            avg_s = step_ms / max(step_n, 1) * 1e-3
-            roof = {'kernel': 'step_kernel', 'bound': 'hbm', 'achieved': per_launch / avg_s / 1e9,
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'avg_launch_ms': step_ms / max(step_n, 1),
-                    'algorithmic_bytes_per_launch': per_launch, 'traffic': None}
-        roof['frac'] = roof['achieved'] / roof['peak']
-        # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process): taken from
-        # the committed summary of the same workload, when one exists for this kernel
-        pmc = sorted((ROOT / 'profiles').glob('r*_pmc_hbm_traffic.json'))
-        if pmc and args.workload == 'stress' and not args.envs:
-            rec = json.loads(pmc[-1].read_text())
-            for kname, d in rec['kernels'].items():
-                if roof['kernel'] in kname:
-                    roof['traffic'] = d['hbm_bytes_per_launch']
-                    roof['traffic_source'] = f'profiles/{pmc[-1].name} (WRITE_SIZE + 2*FETCH_SIZE, separate --pmc passes)'
+            avg_ms = step_ms / max(step_n, 1)
+            roof = {'kernel': 'step_kernel'}
+        ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roof.update({'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                     'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': per_launch, 'traffic': None,
+                     'timing': 'HIP events around every launch on the library stream, ' +
+                               ('inside the timed region' if events_in_timed else
+                                'in a second pass over the same steps (the timed region itself runs without events)')})
+        if not stub:
+            attach_traffic(roof, args, w)
         out = {
             'metric': 'env agent-steps/sec (batch x agents)', 'value': value, 'unit': 'agent-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -222,6 +407,8 @@ def main():
                        'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else 'LogDistance(ple=2)',
                        'positions': 'redrawn on the device every 10 steps' if args.with_reset else 'fixed over the run',
                        'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
+                       'cue_actions': cue_mode + (' (UplinkTrafficModel round-robin, held in the kernel\'s link records; agents supply DUE actions only)'
+                                                  if cue_mode == 'traffic' else ' (agents supply CUE and DUE actions)'),
                        'parallelism': f'env-shard x{world}' + (' + per-step all-gather(reward, sinr/snr columns of the obs table; position columns once per episode)'
                                                                      if gatherer else '')},
             'roofline': roof,
@@ -230,14 +417,74 @@ def main():
             'status_flags': flags,
             'target_agent_steps_per_s': 1e7,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(w)
+        out.update(dist_info)
+        if stub:
+            out['stub'] = 'CPU plumbing test - not a measurement'
+        if single_ms is not None:
+            out['single_env_step_ms'] = single_ms
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)                 # the real stdout is back for the one line that belongs there
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)                            # teardown chatter (RCCL / ROCm) goes to stderr again
+    env.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def attach_traffic(roof, args, w):
+    """HBM bytes per launch come from rocprofv3 PMC passes, which cannot be collected from inside this process: the
+    figure is taken from the newest committed summary for this kernel and workload, but only if that summary was
+    made from the SAME kernel sources that are running now (digest of csrc/ recorded by tools/summarize_profiles.py);
+    otherwise it stays null and the mismatch is reported."""
+    if args.envs:
+        return
+    from gym_d2d_amd.build import source_digest
+    digest = source_digest()
+    for path in sorted((ROOT / 'profiles').glob('r*_pmc_*.json'), reverse=True):
+        try:
+            rec = json.loads(path.read_text())
+        except Exception:
+            continue
+        if rec.get('workload_key') != f'{args.workload}/{args.obs}':
+            continue
+        for kname, d in rec.get('kernels', {}).items():
+            if roof['kernel'] in kname and 'hbm_bytes_per_launch' in d:
+                if rec.get('source_digest') == digest:
+                    roof['traffic'] = d['hbm_bytes_per_launch']
+                    roof['traffic_source'] = (f'profiles/{path.name} (WRITE_SIZE + 2*FETCH_SIZE, separate --pmc passes; '
+                                              f'kernel sources {digest[:12]} = the ones running)')
+                else:
+                    roof['traffic_stale'] = (f'profiles/{path.name} was collected for kernel sources '
+                                             f'{str(rec.get("source_digest"))[:12]}, running {digest[:12]}')
+                return
+
+
+def single_env_latency(c, p, r, ordinal, steps=200):
+    """ms per D2DEnv.step of the drop-in single env (host dicts in / out, PCIe and Python included)."""
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': ordinal})
+    obs = env.reset()
+    rng = np.random.default_rng(0)
+    acts = [{k: int(rng.integers(0, env.action_space['due' if k.startswith('due') else 'cue'].n)) for k in obs}
+            for _ in range(8)]
+    for k in range(5):
+        env.step(acts[k % 8])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(acts[k % 8])
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    env.close()
+    return ms
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))
+    worker(args)
 
 
 if __name__ == '__main__':

@@ -9,7 +9,7 @@ from typing import Optional
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libd2d_hip.so'
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LINKS = 2048
 
 # d2d_status
@@ -25,7 +25,9 @@ OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
  BUF_REWARD, BUF_OBS_TABLE, BUF_OBS, BUF_ENV_FLAGS, BUF_COUNT) = range(14)
 FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
 (TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK, TUNE_OBS_VARIANT,
- TUNE_STEP_THREADS) = range(6)
+ TUNE_STEP_THREADS, TUNE_STEP_ENVS_PER_WG, TUNE_STEP_BLOCK, TUNE_STEP_VARIANT, TUNE_STEP_FUSE_OBS) = range(10)
+STEP_MASK_WALK, STEP_RB_SORTED = 0, 1
+UNIQUE_ID_BYTES = 128
 
 BUFFER_DTYPES = {BUF_ACTIONS: np.int32, BUF_RB: np.int32, BUF_PWR: np.int32, BUF_ENV_FLAGS: np.int32}
 
@@ -37,6 +39,12 @@ class Config(C.Structure):
         ('max_links', C.c_int32), ('pwr_levels_due', C.c_int32), ('pwr_levels_cue', C.c_int32),
         ('pwr_levels_mbs', C.c_int32), ('cell_radius_m', C.c_float), ('d2d_radius_m', C.c_float),
     ]
+
+
+class HostLayout(C.Structure):
+    """d2d_host_layout: byte offsets of every result inside the pinned block d2d_step_host returns."""
+    _fields_ = [(name, C.c_size_t) for name in ('sinr_db', 'snr_db', 'rate_bps', 'capacity', 'reward', 'rb', 'pwr',
+                                                 'obs_table', 'env_flags', 'obs', 'total_bytes')]
 
 
 class NativeError(RuntimeError):
@@ -65,6 +73,8 @@ SIGNATURES = {
     'd2d_set_path_loss_table': (C.c_int, [_P, _FP, _I]),
     'd2d_set_path_loss_shadowing': (C.c_int, [_P, _I, _DP, _DP, _DP, C.c_double, C.c_double, C.c_uint64]),
     'd2d_set_links': (C.c_int, [_P, _I, _IP, _IP, _IP]),
+    'd2d_set_fixed_actions': (C.c_int, [_P, _I, _IP, _IP, _IP]),
+    'd2d_positions_changed': (C.c_int, [_P]),
     'd2d_set_reward': (C.c_int, [_P, _I, C.c_float]),
     'd2d_set_obs_mode': (C.c_int, [_P, _I]),
     'd2d_set_bucketing': (C.c_int, [_P, _I]),
@@ -78,7 +88,13 @@ SIGNATURES = {
     'd2d_set_env_offset': (C.c_int, [_P, C.c_uint64]),
     'd2d_step': (C.c_int, [_P, _P]),
     'd2d_step_rb_pwr': (C.c_int, [_P, _P, _P]),
+    'd2d_expand_table': (C.c_int, [_P, _P, _I, _I, _P]),
+    'd2d_step_host': (C.c_int, [_P, _IP, _IP, C.POINTER(_P), C.POINTER(HostLayout)]),
     'd2d_status_flags': (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    'd2d_comm_unique_id': (C.c_int, [_P]),
+    'd2d_comm_init': (C.c_int, [_P, _I, _I, _P]),
+    'd2d_comm_destroy': (C.c_int, [_P]),
+    'd2d_allgather': (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     'd2d_profile_enable': (C.c_int, [_P, _I]),
     'd2d_profile_read': (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'd2d_profile_reset': (C.c_int, [_P]),
@@ -131,6 +147,7 @@ class Handle:
         self.num_devices = 1 + num_cues + 2 * num_due_pairs
         self.max_links = max_links or (num_cues + num_due_pairs)
         self.num_links = 0
+        self.num_fixed = 0
 
     # -- lifetime
     def close(self) -> None:
@@ -176,6 +193,19 @@ class Handle:
         n = len(a[0])
         _check(self._lib.d2d_set_links(self._h, n, *[c.ctypes.data_as(_IP) for c in a]))
         self.num_links = n
+        self.num_fixed = 0
+
+    def set_fixed_actions(self, link_idx, rb, pwr_dbm) -> None:
+        """Links driven by the traffic model: d2d_step then takes actions for the other links only."""
+        a = [np.ascontiguousarray(c, dtype=np.int32) for c in (link_idx, rb, pwr_dbm)]
+        n = len(a[0])
+        if len(a[1]) != n or len(a[2]) != n:
+            raise ValueError('link_idx, rb and pwr_dbm must have the same length')
+        _check(self._lib.d2d_set_fixed_actions(self._h, n, *[c.ctypes.data_as(_IP) for c in a]))
+        self.num_fixed = n
+
+    def positions_changed(self) -> None:
+        _check(self._lib.d2d_positions_changed(self._h))
 
     def set_reward(self, reward_fn: int, param: float = 0.0) -> None:
         _check(self._lib.d2d_set_reward(self._h, reward_fn, param))
@@ -200,6 +230,8 @@ class Handle:
             return (b, n, 6 * n)
         if which == BUF_ENV_FLAGS:
             return (b,)
+        if which == BUF_ACTIONS:
+            return (b, n - self.num_fixed)
         return (b, n)
 
     def get_buffer(self, which: int):
@@ -250,6 +282,49 @@ class Handle:
 
     def step_rb_pwr(self, rb_ptr: int = 0, pwr_ptr: int = 0) -> None:
         _check(self._lib.d2d_step_rb_pwr(self._h, _P(rb_ptr or None), _P(pwr_ptr or None)))
+
+    def expand_table(self, table_ptr: int, n_envs: int, n_links: int, obs_ptr: int) -> None:
+        _check(self._lib.d2d_expand_table(self._h, _P(table_ptr), n_envs, n_links, _P(obs_ptr)))
+
+    def step_host(self, rb: np.ndarray, pwr: np.ndarray) -> dict:
+        """One step with host (rb, pwr) [B,N] in and every result back in one pinned block.  The returned arrays are
+        VIEWS into library-owned pinned memory, valid until the next step_host on this handle."""
+        b, n = self.num_envs, self.num_links
+        r = np.ascontiguousarray(rb, dtype=np.int32); p = np.ascontiguousarray(pwr, dtype=np.int32)
+        if r.shape != (b, n) or p.shape != (b, n):
+            raise ValueError(f'rb/pwr must be [{b},{n}]')
+        out, lay = _P(), HostLayout()
+        _check(self._lib.d2d_step_host(self._h, r.ctypes.data_as(_IP), p.ctypes.data_as(_IP), C.byref(out), C.byref(lay)))
+        raw = (C.c_char * lay.total_bytes).from_address(out.value)
+
+        def view(off, dtype, shape):
+            return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape)), offset=off).reshape(shape)
+        res = {name: view(getattr(lay, name), np.float32, (b, n))
+               for name in ('sinr_db', 'snr_db', 'rate_bps', 'capacity', 'reward')}
+        res['rb'] = view(lay.rb, np.int32, (b, n)); res['pwr'] = view(lay.pwr, np.int32, (b, n))
+        res['obs_table'] = view(lay.obs_table, np.float32, (b, n, 6))
+        res['env_flags'] = view(lay.env_flags, np.int32, (b,))
+        if lay.total_bytes > lay.obs:
+            res['obs'] = view(lay.obs, np.float32, (b, n, 6 * n))
+        return res
+
+    # -- multi-GPU (RCCL behind the C ABI)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        _check(load_library().d2d_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, world_size: int, rank: int, unique_id: bytes) -> None:
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError(f'unique_id must be {UNIQUE_ID_BYTES} bytes')
+        _check(self._lib.d2d_comm_init(self._h, world_size, rank, C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)))
+
+    def comm_destroy(self) -> None:
+        _check(self._lib.d2d_comm_destroy(self._h))
+
+    def allgather(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream_ptr: int = 0) -> None:
+        _check(self._lib.d2d_allgather(self._h, _P(send_ptr), _P(recv_ptr), bytes_per_rank, _P(stream_ptr or None)))
 
     def status_flags(self) -> int:
         f = C.c_uint32()

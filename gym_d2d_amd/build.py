@@ -30,7 +30,8 @@ def _hipcc() -> str:
     raise RuntimeError('hipcc not found: libd2d_hip.so cannot be built (there is no CPU fallback)')
 
 
-def _digest() -> str:
+def source_digest() -> str:
+    """sha256 over the kernel / C-ABI sources, headers and compile flags: identifies what a profile was taken on."""
     h = hashlib.sha256()
     for p in [CSRC / s for s in SOURCES if (CSRC / s).exists()] + HEADERS:
         h.update(p.name.encode()); h.update(p.read_bytes())
@@ -41,7 +42,7 @@ def _digest() -> str:
 def build(force: bool = False, verbose: bool = False) -> Path:
     LIB_DIR.mkdir(exist_ok=True)
     stamp = LIB_DIR / 'libd2d_hip.sha256'
-    digest = _digest()
+    digest = source_digest()
     if not force and LIB_PATH.exists() and stamp.exists() and stamp.read_text().strip() == digest:
         return LIB_PATH
     hipcc = _hipcc()

@@ -4,6 +4,8 @@
 #include "../../include/d2d_hip.h"
 #include "d2d_internal.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,9 +29,25 @@ int fail(int code, const std::string& msg) {
             return fail(D2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
 
-// Every entry point that may touch HIP first makes the handle's GPU current for the calling thread: with one
-// process per GPU this is a no-op, but a caller that juggles several devices must not redirect our launches.
-#define USE_DEVICE(h) HIP_TRY(hipSetDevice((h)->cfg.device_ordinal))
+// Every entry point that may touch HIP makes the handle's GPU current for the calling thread for the duration of
+// the call and puts the caller's device back on exit: a process that holds handles or torch tensors on several GPUs
+// must not find its current device changed behind its back (torch reads it through hipGetDevice).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int want) {
+        err = hipGetDevice(&prev);
+        if (err != hipSuccess) { prev = -1; return; }
+        if (prev != want) err = hipSetDevice(want); else prev = -1;     // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define USE_DEVICE(h)                                                                                \
+    DeviceGuard device_guard_((h)->cfg.device_ordinal);                                              \
+    if (device_guard_.err != hipSuccess)                                                             \
+        return fail(D2D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_guard_.err))
 
 struct Buffer {
     void* ptr = nullptr;
@@ -51,16 +69,18 @@ struct d2d_handle {
     hipStream_t stream = nullptr;
     Buffer buf[D2D_BUF_COUNT];
     // device-side tables
-    float* dev_cols = nullptr;      // per-link constants, 7 arrays x Nmax (see refresh_tables)
-    int* link_tab = nullptr;        // 3 x Nmax
-    float* pow10_tab = nullptr;     // 128
+    float4* rec = nullptr;          // per-link records: 3 rows of Nmax x 16 B (d2d_internal.h), see refresh_tables
+    float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
+    bool lpos_dirty = true;
     float* gain_table = nullptr;
     size_t gain_elems = 0;
     int table_per_env = 0;
     unsigned* status = nullptr;
     // host-side copies used to derive the device columns
     std::vector<double> eirp_off, rx_off, noise, sens, bw, a_tx, a_rx, expo;
-    std::vector<int> host_tx, host_rx;   // host copy of the link table
+    std::vector<int> host_tx, host_rx, host_type;   // host copy of the link table
+    std::vector<int> fixed_rb, fixed_pwr;            // per link; fixed_rb[i] == INT32_MIN <=> agent-driven
+    int n_fixed = 0;
     bool have_dev = false, have_pl = false, have_links = false, have_pos = false, tables_dirty = true;
     d2d::PlMode mode = d2d::PL_INV_SQUARE;
     int reward_fn = D2D_REWARD_SYSTEM_CAPACITY;
@@ -68,6 +88,14 @@ struct d2d_handle {
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
+    int tune_step_epw = 0, tune_step_block = 0, tune_step_variant = -1, tune_step_fuse = -1;
+    // d2d_step_host: packed device block + pinned host mirrors
+    void* host_out_dev = nullptr; size_t host_out_bytes = 0;
+    void* host_out_pinned = nullptr;
+    int32_t* host_in_dev = nullptr; int32_t* host_in_pinned = nullptr; size_t host_in_bytes = 0;
+    // RCCL communicator (d2d_comm_init)
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
     unsigned long long env_offset = 0;
     double shadow_chi = 0, shadow_d0 = 0;
     unsigned long long shadow_seed = 0, shadow_step = 0;
@@ -129,23 +157,43 @@ int refresh_tables(d2d_handle* h) {
         if (h->mode != d2d::PL_TABLE && h->expo[d] != 2.0) all_two = false;
     }
     if (h->mode != d2d::PL_TABLE && h->mode != d2d::PL_SHADOW) h->mode = all_two ? d2d::PL_INV_SQUARE : d2d::PL_POWER;
-    // flatten to per-link arrays [7][Nmax]: tx-side columns by the link's tx device, rx-side by its rx device, so
-    // the kernel reads them coalesced by link index with no link -> device -> column double hop
+    // Per-link records, 3 rows of [Nmax] x 16 B (layout: d2d_internal.h).  tx-side columns by the link's tx device,
+    // rx-side by its rx device, so the kernel reads them coalesced by link index with no link -> device -> column
+    // double hop; a link with a fixed action carries (rb, pwr) here, the others their column in the action array.
     const int N = h->N, S = h->Nmax;
-    std::vector<float> lk((size_t)7 * S, 0.0f);
+    std::vector<float> rec((size_t)3 * S * 4, 0.0f);
+    int32_t* ra = reinterpret_cast<int32_t*>(rec.data());
+    float* rb = rec.data() + (size_t)S * 4;
+    float* rc = rec.data() + (size_t)2 * S * 4;
+    int col = 0;
     for (int i = 0; i < N; ++i) {
         const int t = h->host_tx[i], r = h->host_rx[i];
-        lk[0 * S + i] = cols[0 * D + t];    // tx_lin
-        lk[1 * S + i] = cols[1 * D + r];    // rx_pl
-        lk[2 * S + i] = cols[2 * D + r];    // rx_lin
-        lk[3 * S + i] = cols[3 * D + r];    // noise_mw
-        lk[4 * S + i] = cols[4 * D + r];    // sens_db
-        lk[5 * S + i] = cols[5 * D + t];    // bw_mhz
-        lk[6 * S + i] = cols[6 * D + t];    // exponent
+        const bool fixed = h->fixed_rb[i] != INT32_MIN;
+        ra[4 * i + 0] = t | (h->host_type[i] << D2D_REC_TYPE_SHIFT) | (fixed ? D2D_REC_FIXED_BIT : 0);
+        ra[4 * i + 1] = r;
+        ra[4 * i + 2] = fixed ? h->fixed_rb[i] : col++;
+        ra[4 * i + 3] = fixed ? h->fixed_pwr[i] : 0;
+        rb[4 * i + 0] = cols[0 * D + t];    // tx_lin
+        rb[4 * i + 1] = cols[1 * D + r];    // rx_pl
+        rb[4 * i + 2] = cols[2 * D + r];    // rx_lin
+        rb[4 * i + 3] = cols[3 * D + r];    // noise_mw
+        rc[4 * i + 0] = cols[4 * D + r];    // sens_db
+        rc[4 * i + 1] = cols[5 * D + t];    // bw_mhz
+        rc[4 * i + 2] = cols[6 * D + t];    // exponent
     }
-    HIP_TRY(hipMemcpyAsync(h->dev_cols, lk.data(), lk.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));   // lk is a stack-lifetime host buffer
+    HIP_TRY(hipMemcpyAsync(h->rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // rec is a stack-lifetime host buffer
     h->tables_dirty = false;
+    h->lpos_dirty = true;                       // the link -> device map may have changed
+    return D2D_OK;
+}
+
+// (Re)build the per-link position rows from POS_X / POS_Y through the link records (one small kernel, only after a
+// reset / set_positions / set_links - simulator.py:61-75 is the only place the reference moves devices).
+int refresh_link_positions(d2d_handle* h, const float* px, const float* py) {
+    if (!h->lpos_dirty) return D2D_OK;
+    HIP_TRY(d2d::launch_link_positions(px, py, reinterpret_cast<const int4*>(h->rec), h->B, h->N, h->D, h->lpos, h->stream));
+    h->lpos_dirty = false;
     return D2D_OK;
 }
 
@@ -184,7 +232,50 @@ int drain_events(d2d_handle* h) {
     return D2D_OK;
 }
 
-int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a1) {
+// Where one step writes its results: the handle's D2D_BUF_* buffers (d2d_step / d2d_step_rb_pwr) or the packed block
+// of d2d_step_host.
+struct OutPtrs {
+    int* rb = nullptr; int* pwr = nullptr;
+    float *sinr = nullptr, *snr = nullptr, *rate = nullptr, *cap = nullptr, *reward = nullptr, *table = nullptr, *obs = nullptr;
+    int* env_flags = nullptr;
+};
+
+// LinearObs expansion launch geometry for a [B, N, 6] table (shared by the step path and d2d_expand_table).
+void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float* obs, d2d::ObsArgs* out) {
+    d2d::ObsArgs o;
+    std::memset(&o, 0, sizeof(o));
+    o.B = B; o.N = N;
+    o.vec = (6 * N) % 4 == 0 ? 4 : 2;
+    o.q_per_row = (unsigned)(6 * N / o.vec);
+    o.q_magic = ((1ull << 40) + o.q_per_row - 1) / o.q_per_row;
+    // Launch geometry (tools/tune_obs.py, MI355X, N = 512): the fastest shape is the one where every thread
+    // issues exactly TWO 16-B stores - block = one row's float4 count (768), 2 rows per workgroup: 6.96 TB/s vs
+    // 5.9 TB/s for 96-KiB slabs and 5.6 TB/s for 786-KiB slabs.  Small slabs dispatched in order keep the
+    // chip-wide write front nearly sequential in address, and a workgroup never outlives its neighbours.
+    int block = h->tune_block;
+    if (block <= 0) {
+        block = (int)((o.q_per_row + 63) / 64) * 64;
+        if (block < 256) block = 256;
+        if (block > 1024) block = 1024;
+    }
+    int rows = h->tune_rows;
+    if (rows <= 0) {
+        rows = (int)((2u * (unsigned)block + o.q_per_row / 2) / o.q_per_row);
+        if (rows < 1) rows = 1;
+    }
+    if (rows > N) rows = N;
+    o.rows_per_wg = rows;
+    o.chunks = (N + rows - 1) / rows;
+    o.xcd_remap = (h->tune_xcd > 0 && B % (8 * h->tune_xcd) == 0) ? h->tune_xcd : 0;   // envs interleaved per XCD
+    o.nontemporal = h->tune_nt;
+    o.block = block;
+    o.variant = h->tune_variant;
+    o.table = table;
+    o.obs = obs;
+    *out = o;
+}
+
+int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a1, const OutPtrs* redirect) {
     if (!h->have_links) return fail(D2D_ERR_STATE, "d2d_set_links has not been called");
     if (!h->have_pos) return fail(D2D_ERR_STATE, "positions not set (d2d_set_positions / upload POS_X,POS_Y)");
     int rc = refresh_tables(h);
@@ -195,19 +286,53 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     d2d::StepArgs s;
     std::memset(&s, 0, sizeof(s));
     s.B = h->B; s.N = N; s.R = h->cfg.num_rbs; s.D = D;
-    int W = 0;
-    if (h->bucketing) {
-        W = (N + 63) / 64;
-        if (d2d::step_lds_bytes(N, s.R, W) > 96 * 1024) W = 0;
-    }
-    s.mask_words = W;
     s.action_mode = action_mode;
+    s.act_stride = action_mode == 0 ? N - h->n_fixed : N;
     s.p_due = h->cfg.pwr_levels_due; s.p_cue = h->cfg.pwr_levels_cue; s.p_mbs = h->cfg.pwr_levels_mbs;
     auto magic = [](int P) -> unsigned long long { return P < 512 ? ((1ull << 40) + (unsigned)P - 1) / (unsigned)P : 0ull; };
     s.m_due = magic(s.p_due); s.m_cue = magic(s.p_cue); s.m_mbs = magic(s.p_mbs);
-    s.threads = h->tune_step_threads;
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
+
+    // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
+    // workgroup (N = 50: four 64-thread envs in 256 threads), and for small N the LinearObs expansion runs inside the
+    // same launch, streamed by all threads of the workgroup - two launches of a few microseconds each are bound by
+    // launch latency, not by HBM.
+    int tpe = h->tune_step_threads > 0 ? h->tune_step_threads : ((N + 63) / 64) * 64;
+    if (tpe > 1024) tpe = 1024;
+    if (tpe < 64) tpe = 64;
+    const bool single = N <= tpe;
+    int fuse = 0;
+    if (h->obs_mode == D2D_OBS_LINEAR) {
+        const bool want = h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128;
+        if (want) fuse = (6 * N) % 4 == 0 ? 4 : 2;
+    }
+    int W = 0;
+    if (h->bucketing) {
+        W = (N + 63) / 64;
+        if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse) > 96 * 1024) W = 0;
+    }
+    const size_t env_lds = d2d::step_lds_bytes_per_env(N, s.R, W, fuse);
+    if (env_lds > 160 * 1024) return fail(D2D_ERR_UNSUPPORTED, "links per env exceed the LDS staging capacity");
+    int epw = h->tune_step_epw;
+    if (epw <= 0) epw = tpe >= 256 ? 1 : 256 / tpe;
+    if (epw > h->B) epw = h->B;
+    while (epw > 1 && ((size_t)epw * env_lds > 64 * 1024 || epw * tpe > 1024)) --epw;
+    int block = h->tune_step_block > 0 ? h->tune_step_block : epw * tpe;
+    if (fuse && h->tune_step_block <= 0 && block < 256) block = 256;      // more store streams per env for the obs phase
+    if (block < epw * tpe) block = epw * tpe;
+    if (block > 1024) return fail(D2D_ERR_INVALID, "step workgroup exceeds 1024 threads");
+    s.tpe = tpe; s.epw = epw; s.mask_words = W; s.fuse_obs = fuse;
+    // interferer search: the RB-sorted buckets need one link per thread and the masks (their ranks); see DESIGN.md 4.1
+    // for the A/B that picked the default
+    int variant = h->tune_step_variant >= 0 ? h->tune_step_variant : d2d::STEP_RB_SORTED;
+    if (!single || W == 0 || N > 65535) variant = d2d::STEP_MASK_WALK;
+    s.variant = variant;
+    if (fuse) {
+        s.obs_q_per_row = (unsigned)(6 * N / fuse);
+        s.obs_q_magic = ((1ull << 40) + s.obs_q_per_row - 1) / s.obs_q_per_row;
+    }
+
     void* p = nullptr;
 #define GET(which, field, type)                                  \
     do {                                                         \
@@ -216,28 +341,47 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         s.field = reinterpret_cast<type>(p);                     \
     } while (0)
     if (action_mode == 0) {
-        if (a0) s.actions = a0; else GET(D2D_BUF_ACTIONS, actions, const int*);
-        GET(D2D_BUF_RB, rb_out, int*);
-        GET(D2D_BUF_PWR, pwr_out, int*);
+        if (s.act_stride == 0) s.actions = nullptr;              // every link is fixed: nothing to read
+        else if (a0) s.actions = a0; else GET(D2D_BUF_ACTIONS, actions, const int*);
     } else {
         if (a0) s.rb_in = a0; else GET(D2D_BUF_RB, rb_in, const int*);
         if (a1) s.pwr_in = a1; else GET(D2D_BUF_PWR, pwr_in, const int*);
     }
-    GET(D2D_BUF_POS_X, pos_x, const float*);
-    GET(D2D_BUF_POS_Y, pos_y, const float*);
-    GET(D2D_BUF_SINR_DB, sinr_db, float*);
-    GET(D2D_BUF_SNR_DB, snr_db, float*);
-    GET(D2D_BUF_RATE_BPS, rate, float*);
-    GET(D2D_BUF_CAPACITY, cap, float*);
-    GET(D2D_BUF_ENV_FLAGS, env_flags, int*);
-    if (s.reward_fn != D2D_REWARD_NONE) GET(D2D_BUF_REWARD, reward, float*);
-    if (s.write_table) GET(D2D_BUF_OBS_TABLE, table, float*);
-    s.link_tx = h->link_tab; s.link_rx = h->link_tab + h->Nmax; s.link_type = h->link_tab + 2 * h->Nmax;
+    rc = ensure_buffer(h, D2D_BUF_POS_X, &p);
+    if (rc) return rc;
+    const float* px = static_cast<const float*>(p);
+    rc = ensure_buffer(h, D2D_BUF_POS_Y, &p);
+    if (rc) return rc;
+    const float* py = static_cast<const float*>(p);
+    if (redirect) {
+        s.rb_out = redirect->rb; s.pwr_out = redirect->pwr;        // decoded / fixed values as the kernel used them
+        s.sinr_db = redirect->sinr; s.snr_db = redirect->snr; s.rate = redirect->rate; s.cap = redirect->cap;
+        s.env_flags = redirect->env_flags;
+        if (s.reward_fn != D2D_REWARD_NONE) s.reward = redirect->reward;
+        if (s.write_table) s.table = redirect->table;
+        if (h->obs_mode == D2D_OBS_LINEAR) s.obs = redirect->obs;
+    } else {
+        if (action_mode == 0) {
+            GET(D2D_BUF_RB, rb_out, int*);
+            GET(D2D_BUF_PWR, pwr_out, int*);
+        }
+        GET(D2D_BUF_SINR_DB, sinr_db, float*);
+        GET(D2D_BUF_SNR_DB, snr_db, float*);
+        GET(D2D_BUF_RATE_BPS, rate, float*);
+        GET(D2D_BUF_CAPACITY, cap, float*);
+        GET(D2D_BUF_ENV_FLAGS, env_flags, int*);
+        if (s.reward_fn != D2D_REWARD_NONE) GET(D2D_BUF_REWARD, reward, float*);
+        if (s.write_table) GET(D2D_BUF_OBS_TABLE, table, float*);
+        if (h->obs_mode == D2D_OBS_LINEAR) GET(D2D_BUF_OBS, obs, float*);
+    }
+#undef GET
+    rc = refresh_link_positions(h, px, py);
+    if (rc) return rc;
     const int S = h->Nmax;
-    s.lk_tx_lin = h->dev_cols; s.lk_rx_pl = h->dev_cols + S; s.lk_rx_lin = h->dev_cols + 2 * S;
-    s.lk_noise_mw = h->dev_cols + 3 * S; s.lk_sens_db = h->dev_cols + 4 * S; s.lk_bw_mhz = h->dev_cols + 5 * S;
-    s.lk_exp = h->dev_cols + 6 * S;
-    s.pow10_tab = h->pow10_tab;
+    s.rec_a = reinterpret_cast<const int4*>(h->rec);
+    s.rec_b = h->rec + S;
+    s.rec_c = h->rec + 2 * (size_t)S;
+    s.lpos = h->lpos;
     s.gain_table = h->gain_table;
     s.table_env_stride = h->table_per_env ? (long long)D * D : 0;
     s.env_offset = h->env_offset;
@@ -252,49 +396,55 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     EventPair* ep = nullptr;
     rc = record_start(h, 0, &ep);
     if (rc) return rc;
-    HIP_TRY(d2d::launch_step(s, h->mode, h->stream));
+    HIP_TRY(d2d::launch_step(s, h->mode, block, h->stream));
     if (ep) HIP_TRY(hipEventRecord(ep->stop, h->stream));
 
-    if (h->obs_mode == D2D_OBS_LINEAR) {
+    if (h->obs_mode == D2D_OBS_LINEAR && !fuse) {
         d2d::ObsArgs o;
-        std::memset(&o, 0, sizeof(o));
-        o.B = h->B; o.N = N;
-        o.vec = (6 * N) % 4 == 0 ? 4 : 2;
-        o.q_per_row = (unsigned)(6 * N / o.vec);
-        o.q_magic = ((1ull << 40) + o.q_per_row - 1) / o.q_per_row;
-        // Launch geometry (tools/tune_obs.py, MI355X, N = 512): the fastest shape is the one where every thread
-        // issues exactly TWO 16-B stores - block = one row's float4 count (768), 2 rows per workgroup: 6.96 TB/s vs
-        // 5.9 TB/s for 96-KiB slabs and 5.6 TB/s for 786-KiB slabs.  Small slabs dispatched in order keep the
-        // chip-wide write front nearly sequential in address, and a workgroup never outlives its neighbours.
-        int block = h->tune_block;
-        if (block <= 0) {
-            block = (int)((o.q_per_row + 63) / 64) * 64;
-            if (block < 256) block = 256;
-            if (block > 1024) block = 1024;
-        }
-        int rows = h->tune_rows;
-        if (rows <= 0) {
-            rows = (int)((2u * (unsigned)block + o.q_per_row / 2) / o.q_per_row);
-            if (rows < 1) rows = 1;
-        }
-        if (rows > N) rows = N;
-        o.rows_per_wg = rows;
-        o.chunks = (N + rows - 1) / rows;
-        o.xcd_remap = (h->tune_xcd > 0 && h->B % (8 * h->tune_xcd) == 0) ? h->tune_xcd : 0;   // envs interleaved per XCD
-        o.nontemporal = h->tune_nt;
-        o.block = block;
-        o.variant = h->tune_variant;
-        o.table = s.table;
-        rc = ensure_buffer(h, D2D_BUF_OBS, &p);
-        if (rc) return rc;
-        o.obs = reinterpret_cast<float*>(p);
+        make_obs_args(h, h->B, N, s.table, s.obs, &o);
         rc = record_start(h, 1, &ep);
         if (rc) return rc;
         HIP_TRY(d2d::launch_obs_expand(o, h->stream));
         if (ep) HIP_TRY(hipEventRecord(ep->stop, h->stream));
     }
-#undef GET
     return D2D_OK;
+}
+
+// ---- RCCL, loaded on first use ------------------------------------------------------------------
+struct Id128 { char bytes[D2D_UNIQUE_ID_BYTES]; };     // ncclUniqueId: passed BY VALUE to ncclCommInitRank
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.lib) return D2D_OK;
+    const char* override_path = std::getenv("D2D_RCCL_LIBRARY");
+    const char* names[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    // a process that already has RCCL mapped (torch.distributed) must share that copy, not load a second one
+    for (const char* n : names) if (n && !lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) if (n && !lib) lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(D2D_ERR_UNSUPPORTED, std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"));
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
+        return fail(D2D_ERR_UNSUPPORTED, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather");
+    g_rccl.lib = lib;
+    return D2D_OK;
+}
+
+int rccl_fail(const char* what, int code) {
+    return fail(D2D_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "rccl error") +
+                                 " (" + std::to_string(code) + ")");
 }
 
 }  // namespace
@@ -320,7 +470,8 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     HIP_TRY(hipGetDeviceCount(&count));
     if (cfg->device_ordinal < 0 || cfg->device_ordinal >= count)
         return fail(D2D_ERR_HIP, "device_ordinal out of range (no usable GPU?)");
-    HIP_TRY(hipSetDevice(cfg->device_ordinal));
+    DeviceGuard device_guard_(cfg->device_ordinal);
+    if (device_guard_.err != hipSuccess) return fail(D2D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_guard_.err));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_ordinal));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -343,14 +494,10 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    CREATE_TRY(hipMalloc(&h->dev_cols, (size_t)7 * h->Nmax * 4));
-    CREATE_TRY(hipMalloc(&h->link_tab, (size_t)3 * h->Nmax * 4));
-    CREATE_TRY(hipMalloc(&h->pow10_tab, 128 * 4));
+    CREATE_TRY(hipMalloc(&h->rec, (size_t)3 * h->Nmax * 16));
+    CREATE_TRY(hipMalloc(&h->lpos, (size_t)h->B * h->Nmax * 16));
     CREATE_TRY(hipMalloc(&h->status, 4));
     CREATE_TRY(hipMemset(h->status, 0, 4));
-    float tab[128];
-    for (int p = 0; p < 128; ++p) tab[p] = (float)std::pow(10.0, p / 10.0);
-    CREATE_TRY(hipMemcpy(h->pow10_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
 #undef CREATE_TRY
     *out = h;
     return D2D_OK;
@@ -358,14 +505,18 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
 
 int d2d_destroy(d2d_handle* h) {
     if (!h) return D2D_OK;
-    hipSetDevice(h->cfg.device_ordinal);
+    DeviceGuard device_guard_(h->cfg.device_ordinal);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto& ep : h->events) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
     for (auto& bf : h->buf)
         if (bf.ptr && bf.owned) hipFree(bf.ptr);
-    if (h->dev_cols) hipFree(h->dev_cols);
-    if (h->link_tab) hipFree(h->link_tab);
-    if (h->pow10_tab) hipFree(h->pow10_tab);
+    if (h->rec) hipFree(h->rec);
+    if (h->lpos) hipFree(h->lpos);
+    if (h->host_out_dev) hipFree(h->host_out_dev);
+    if (h->host_out_pinned) hipHostFree(h->host_out_pinned);
+    if (h->host_in_dev) hipFree(h->host_in_dev);
+    if (h->host_in_pinned) hipHostFree(h->host_in_pinned);
     if (h->gain_table) hipFree(h->gain_table);
     if (h->status) hipFree(h->status);
     if (h->fixed_mask_dev) hipFree(h->fixed_mask_dev);
@@ -462,16 +613,41 @@ int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const i
             return fail(D2D_ERR_INVALID, "link " + std::to_string(i) + ": link_type must be 1, 2 or 3");
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (n_links > 0) {
-        HIP_TRY(hipMemcpy(h->link_tab, tx_dev, (size_t)n_links * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->link_tab + h->Nmax, rx_dev, (size_t)n_links * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->link_tab + 2 * h->Nmax, link_type, (size_t)n_links * 4, hipMemcpyHostToDevice));
-    }
     h->N = n_links;
     h->host_tx.assign(tx_dev, tx_dev + n_links);
     h->host_rx.assign(rx_dev, rx_dev + n_links);
-    h->tables_dirty = true;          // per-link constant arrays follow the link table
+    h->host_type.assign(link_type, link_type + n_links);
+    h->fixed_rb.assign((size_t)n_links, INT32_MIN);
+    h->fixed_pwr.assign((size_t)n_links, 0);
+    h->n_fixed = 0;
+    h->tables_dirty = true;          // the per-link records follow the link table (uploaded by the next step)
+    h->lpos_dirty = true;
     h->have_links = true;
+    return D2D_OK;
+}
+
+int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_idx, const int32_t* rb, const int32_t* pwr_dbm) {
+    if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    if (!h->have_links) return fail(D2D_ERR_STATE, "d2d_set_links first: fixed actions refer to its link list");
+    if (n_fixed < 0 || n_fixed > h->N) return fail(D2D_ERR_INVALID, "n_fixed must be in [0, n_links]");
+    if (n_fixed > 0 && (!link_idx || !rb || !pwr_dbm)) return fail(D2D_ERR_INVALID, "null argument");
+    std::vector<int> frb((size_t)h->N, INT32_MIN), fpw((size_t)h->N, 0);
+    for (int k = 0; k < n_fixed; ++k) {
+        const int i = link_idx[k];
+        if (i < 0 || i >= h->N) return fail(D2D_ERR_INVALID, "fixed action " + std::to_string(k) + ": link index out of range");
+        if (frb[i] != INT32_MIN) return fail(D2D_ERR_INVALID, "fixed action " + std::to_string(k) + ": link listed twice");
+        if (rb[k] == INT32_MIN) return fail(D2D_ERR_INVALID, "rb out of range");
+        frb[i] = rb[k]; fpw[i] = pwr_dbm[k];
+    }
+    h->fixed_rb.swap(frb); h->fixed_pwr.swap(fpw);
+    h->n_fixed = n_fixed;
+    h->tables_dirty = true;
+    return D2D_OK;
+}
+
+int d2d_positions_changed(d2d_handle* h) {
+    if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    h->lpos_dirty = true;
     return D2D_OK;
 }
 
@@ -514,6 +690,22 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
             if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "block must be a multiple of 64 in [64,1024]");
             h->tune_block = value;
             break;
+        case D2D_TUNE_STEP_ENVS_PER_WG:
+            if (value < 0 || value > 16) return fail(D2D_ERR_INVALID, "envs per workgroup must be in [0,16]");
+            h->tune_step_epw = value;
+            break;
+        case D2D_TUNE_STEP_BLOCK:
+            if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "block must be a multiple of 64 in [64,1024]");
+            h->tune_step_block = value;
+            break;
+        case D2D_TUNE_STEP_VARIANT:
+            if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "variant must be -1, 0 or 1");
+            h->tune_step_variant = value;
+            break;
+        case D2D_TUNE_STEP_FUSE_OBS:
+            if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "fuse_obs must be -1, 0 or 1");
+            h->tune_step_fuse = value;
+            break;
         default: return fail(D2D_ERR_INVALID, "unknown tuning key");
     }
     return D2D_OK;
@@ -538,8 +730,10 @@ int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (bf.ptr && bf.owned) HIP_TRY(hipFree(bf.ptr));
     bf.ptr = dev_ptr; bf.bytes = dev_ptr ? bytes : 0; bf.owned = false;
-    if (which == D2D_BUF_POS_X || which == D2D_BUF_POS_Y)
+    if (which == D2D_BUF_POS_X || which == D2D_BUF_POS_Y) {
         h->have_pos = h->buf[D2D_BUF_POS_X].ptr && h->buf[D2D_BUF_POS_Y].ptr;
+        h->lpos_dirty = true;
+    }
     return D2D_OK;
 }
 
@@ -553,8 +747,10 @@ int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes,
     if (dst_offset + bytes > h->buf[which].bytes) return fail(D2D_ERR_INVALID, "upload out of range");
     HIP_TRY(hipMemcpyAsync(static_cast<char*>(p) + dst_offset, host_src, bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (which == D2D_BUF_POS_X || which == D2D_BUF_POS_Y)
+    if (which == D2D_BUF_POS_X || which == D2D_BUF_POS_Y) {
         h->have_pos = h->buf[D2D_BUF_POS_X].ptr && h->buf[D2D_BUF_POS_Y].ptr;
+        h->lpos_dirty = true;
+    }
     return D2D_OK;
 }
 
@@ -610,14 +806,16 @@ int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const ui
     HIP_TRY(d2d::launch_reset(h->B, h->D, h->cfg.num_cues, h->cfg.cell_radius_m, h->cfg.d2d_radius_m, seed, episode,
                               h->env_offset, m, xy, static_cast<float*>(px), static_cast<float*>(py), h->stream));
     h->have_pos = true;
+    h->lpos_dirty = true;
     return D2D_OK;
 }
 
 int d2d_step(d2d_handle* h, const int32_t* actions_dev) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
-    if (!actions_dev && !h->buf[D2D_BUF_ACTIONS].ptr) return fail(D2D_ERR_STATE, "no actions: pass a pointer or fill D2D_BUF_ACTIONS");
-    return run_step(h, 0, actions_dev, nullptr);
+    if (!actions_dev && !h->buf[D2D_BUF_ACTIONS].ptr && h->n_fixed < h->N)
+        return fail(D2D_ERR_STATE, "no actions: pass a pointer or fill D2D_BUF_ACTIONS");
+    return run_step(h, 0, actions_dev, nullptr, nullptr);
 }
 
 int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev) {
@@ -625,7 +823,114 @@ int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev
     USE_DEVICE(h);
     if ((!rb_dev && !h->buf[D2D_BUF_RB].ptr) || (!pwr_dev && !h->buf[D2D_BUF_PWR].ptr))
         return fail(D2D_ERR_STATE, "no rb/pwr: pass pointers or fill D2D_BUF_RB / D2D_BUF_PWR");
-    return run_step(h, 1, rb_dev, pwr_dev);
+    return run_step(h, 1, rb_dev, pwr_dev, nullptr);
+}
+
+int d2d_expand_table(d2d_handle* h, const float* table_dev, int32_t n_envs, int32_t n_links, float* obs_dev) {
+    if (!h || !table_dev || !obs_dev) return fail(D2D_ERR_INVALID, "null argument");
+    if (n_envs < 1 || n_links < 1 || n_links > D2D_MAX_LINKS) return fail(D2D_ERR_INVALID, "n_envs >= 1 and 1 <= n_links <= D2D_MAX_LINKS");
+    USE_DEVICE(h);
+    d2d::ObsArgs o;
+    make_obs_args(h, n_envs, n_links, table_dev, obs_dev, &o);
+    EventPair* ep = nullptr;
+    int rc = record_start(h, 1, &ep);
+    if (rc) return rc;
+    HIP_TRY(d2d::launch_obs_expand(o, h->stream));
+    if (ep) HIP_TRY(hipEventRecord(ep->stop, h->stream));
+    return D2D_OK;
+}
+
+int d2d_step_host(d2d_handle* h, const int32_t* rb_host, const int32_t* pwr_host, const void** out_host, d2d_host_layout* layout) {
+    if (!h || !rb_host || !pwr_host || !out_host || !layout) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
+    if (!h->have_links) return fail(D2D_ERR_STATE, "d2d_set_links has not been called");
+    const size_t bn = (size_t)h->B * h->N;
+    if (bn == 0) return fail(D2D_ERR_INVALID, "no links: the reference divides by len(actions) (reward_fn.py:42)");
+    d2d_host_layout L;
+    L.sinr_db = 0; L.snr_db = bn * 4; L.rate_bps = 2 * bn * 4; L.capacity = 3 * bn * 4; L.reward = 4 * bn * 4;
+    L.rb = 5 * bn * 4; L.pwr = 6 * bn * 4; L.obs_table = 7 * bn * 4; L.env_flags = 13 * bn * 4;
+    L.obs = (L.env_flags + (size_t)h->B * 4 + 15) & ~(size_t)15;
+    L.total_bytes = L.obs + (h->obs_mode == D2D_OBS_LINEAR ? bn * 6 * (size_t)h->N * 4 : 0);
+    if (h->host_out_bytes < L.total_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->host_out_dev) HIP_TRY(hipFree(h->host_out_dev));
+        if (h->host_out_pinned) HIP_TRY(hipHostFree(h->host_out_pinned));
+        h->host_out_dev = nullptr; h->host_out_pinned = nullptr; h->host_out_bytes = 0;
+        HIP_TRY(hipMalloc(&h->host_out_dev, L.total_bytes));
+        HIP_TRY(hipHostMalloc(&h->host_out_pinned, L.total_bytes, hipHostMallocDefault));
+        h->host_out_bytes = L.total_bytes;
+    }
+    if (h->host_in_bytes < 2 * bn * 4) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->host_in_dev) HIP_TRY(hipFree(h->host_in_dev));
+        if (h->host_in_pinned) HIP_TRY(hipHostFree(h->host_in_pinned));
+        h->host_in_dev = nullptr; h->host_in_pinned = nullptr; h->host_in_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->host_in_dev), 2 * bn * 4));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_in_pinned), 2 * bn * 4, hipHostMallocDefault));
+        h->host_in_bytes = 2 * bn * 4;
+    }
+    std::memcpy(h->host_in_pinned, rb_host, bn * 4);
+    std::memcpy(h->host_in_pinned + bn, pwr_host, bn * 4);
+    HIP_TRY(hipMemcpyAsync(h->host_in_dev, h->host_in_pinned, 2 * bn * 4, hipMemcpyHostToDevice, h->stream));
+    char* base = static_cast<char*>(h->host_out_dev);
+    OutPtrs o;
+    o.sinr = reinterpret_cast<float*>(base + L.sinr_db); o.snr = reinterpret_cast<float*>(base + L.snr_db);
+    o.rate = reinterpret_cast<float*>(base + L.rate_bps); o.cap = reinterpret_cast<float*>(base + L.capacity);
+    o.reward = reinterpret_cast<float*>(base + L.reward);
+    o.rb = reinterpret_cast<int*>(base + L.rb); o.pwr = reinterpret_cast<int*>(base + L.pwr);
+    o.table = reinterpret_cast<float*>(base + L.obs_table);
+    o.env_flags = reinterpret_cast<int*>(base + L.env_flags);
+    o.obs = reinterpret_cast<float*>(base + L.obs);
+    int rc = run_step(h, 1, h->host_in_dev, h->host_in_dev + bn, &o);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->host_out_pinned, h->host_out_dev, L.total_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *out_host = h->host_out_pinned;
+    *layout = L;
+    return D2D_OK;
+}
+
+int d2d_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(D2D_ERR_INVALID, "null argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    const int e = g_rccl.GetUniqueId(id_out);
+    return e ? rccl_fail("ncclGetUniqueId", e) : D2D_OK;
+}
+
+int d2d_comm_init(d2d_handle* h, int32_t world_size, int32_t rank, const void* unique_id) {
+    if (!h || !unique_id) return fail(D2D_ERR_INVALID, "null argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(D2D_ERR_INVALID, "rank must be in [0, world_size)");
+    USE_DEVICE(h);
+    int rc = load_rccl();
+    if (rc) return rc;
+    if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    Id128 id;
+    std::memcpy(id.bytes, unique_id, sizeof(id.bytes));
+    const int e = g_rccl.CommInitRank(&h->comm, world_size, id, rank);
+    if (e) { h->comm = nullptr; return rccl_fail("ncclCommInitRank", e); }
+    h->comm_world = world_size; h->comm_rank = rank;
+    return D2D_OK;
+}
+
+int d2d_comm_destroy(d2d_handle* h) {
+    if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    USE_DEVICE(h);
+    if (h->comm) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    return D2D_OK;
+}
+
+int d2d_allgather(d2d_handle* h, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* hip_stream) {
+    if (!h || !send_dev || !recv_dev) return fail(D2D_ERR_INVALID, "null argument");
+    if (!h->comm) return fail(D2D_ERR_STATE, "d2d_comm_init has not been called");
+    USE_DEVICE(h);
+    hipStream_t stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->stream;
+    const int e = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, /* ncclInt8 */ 0, h->comm, stream);
+    return e ? rccl_fail("ncclAllGather", e) : D2D_OK;
 }
 
 int d2d_status_flags(d2d_handle* h, uint32_t* flags) {

@@ -13,36 +13,51 @@ enum PlMode : int {
     PL_SHADOW = 3        // PL_POWER + log-normal shadowing beyond d0, fresh Philox Gaussian per evaluation
 };
 
+// How same-RB interferers are found (results are bit-identical; d2d_set_tuning(D2D_TUNE_STEP_VARIANT)).
+enum StepVariant : int {
+    STEP_MASK_WALK = 0,  // per-RB membership bitmasks, walked with ctz (summary word -> mask word -> tuple)
+    STEP_RB_SORTED = 1   // stable counting sort by RB (mask popcount ranks + wave scan), contiguous bucket reads
+};
+
+// Per-link record, three 16-byte rows shared by all envs and read coalesced by link index (L2-resident).  Built on
+// the host from the per-device columns + the link table whenever links, tables or fixed actions change.
+//   a (int4)   x: tx device | link_type << 24 | fixed << 28     y: rx device
+//              z: fixed ? rb : column of this link in the raw action array       w: fixed ? tx power dBm : 0
+//   b (float4) x: tx_lin = 10^((eirp_off - a_tx)/10)   y: rx_pl = 10^(-a_rx/10)   z: rx_lin = 10^(rx_off/10)
+//              w: noise_mw = 10^(thermal_noise_dBm/10)
+//   c (float4) x: rx_sensitivity_dBm   y: 1e-6 * RB bandwidth (Hz) of the tx   z: path-loss exponent of the tx   w: -
+#define D2D_REC_TXDEV_MASK 0x00FFFFFF
+#define D2D_REC_TYPE_SHIFT 24
+#define D2D_REC_TYPE_MASK 0xF
+#define D2D_REC_FIXED_BIT (1 << 28)
+
 struct StepArgs {
     // geometry
     int B, N, R, D;
     int mask_words;          // ceil(N/64): u64 words per RB membership mask (0 -> all-pairs path)
     int action_mode;         // 0: raw int actions (a // P, a % P)   1: explicit rb / pwr
+    int act_stride;          // columns of the action array(s): N - n_fixed in mode 0, N in mode 1
     int p_due, p_cue, p_mbs; // power levels per link type (d2d_env.py:31-35)
     unsigned long long m_due, m_cue, m_mbs;   // ceil(2^40 / P) division magics (0 -> use the hardware divide)
-    int threads;             // threads per workgroup (0 -> one per link, rounded up to a wave, max 1024)
+    int tpe;                 // threads per env (multiple of 64, <= 1024)
+    int epw;                 // envs per workgroup (epw * tpe <= blockDim)
+    int variant;             // StepVariant
     int reward_fn;
     float reward_param;
     int write_table;
+    // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)
+    int fuse_obs;
+    unsigned obs_q_per_row;          // 6N / fuse_obs
+    unsigned long long obs_q_magic;  // ceil(2^40 / obs_q_per_row)
     // inputs
-    const int* actions;      // [B,N]
-    const int* rb_in;        // [B,N]
-    const int* pwr_in;       // [B,N]
-    const int* link_tx;      // [N] device index
-    const int* link_rx;      // [N]
-    const int* link_type;    // [N] 1 uplink, 2 downlink, 3 sidelink
-    const float* pos_x;      // [B,D]
-    const float* pos_y;      // [B,D]
-    // per-link constants [N], flattened on the host from the per-device columns whenever links or tables change
-    const float* lk_tx_lin;    // 10^((eirp_off - a_tx)/10) of the tx device: EIRP offset + tx side of the path-loss constant
-    const float* lk_rx_pl;     // 10^(-a_rx/10) of the rx device: rx side of the path-loss constant (signal AND interference)
-    const float* lk_rx_lin;    // 10^(rx_off/10): rx antenna/body/cable terms (signal only, simulator.py:93 vs :100)
-    const float* lk_noise_mw;  // 10^(thermal_noise_dBm/10) of the rx device
-    const float* lk_sens_db;   // rx_sensitivity_dBm of the rx device
-    const float* lk_bw_mhz;    // 1e-6 * RB bandwidth (Hz) of the tx device
-    const float* lk_exp;       // path-loss exponent of the tx device
-    const float* pow10_tab;    // [128] 10^(p/10) for integer p dBm
-    const float* gain_table;   // PL_TABLE: linear gain [D,D] (tx major)
+    const int* actions;      // [B, act_stride]
+    const int* rb_in;        // [B, N]
+    const int* pwr_in;       // [B, N]
+    const int4* rec_a;       // [N]
+    const float4* rec_b;     // [N]
+    const float4* rec_c;     // [N]
+    const float4* lpos;      // [B, N] (tx_x, tx_y, rx_x, rx_y) of every link, rebuilt when positions / links change
+    const float* gain_table; // PL_TABLE: linear gain [D,D] (tx major)
     long long table_env_stride; // 0 or D*D
     // PL_SHADOW (ShadowingPathLoss, path_loss.py:69-81)
     float shadow_chi;        // std of the shadowing term, dB
@@ -58,6 +73,7 @@ struct StepArgs {
     float* cap;
     float* reward;           // [B,N] (nullable when reward_fn == 0)
     float* table;            // [B,N,6]
+    float* obs;              // [B,N,6N] (fuse_obs only)
     int* env_flags;          // [B]  (OR-reduced on demand by launch_flags_or)
 };
 
@@ -76,11 +92,13 @@ struct ObsArgs {
     float* obs;              // [B,N,6N]
 };
 
-hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream);
+hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream);
-size_t step_lds_bytes(int N, int R, int mask_words);
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs);
 hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);
+hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const int4* rec_a, int B, int N, int D,
+                                 float4* lpos, hipStream_t stream);
 hipError_t launch_reset(int B, int D, int C, float cell_radius, float d2d_radius, unsigned long long seed,
                         unsigned long long episode, unsigned long long env_offset, const unsigned char* fixed_mask,
                         const float* fixed_xy, float* pos_x, float* pos_y, hipStream_t stream);

@@ -6,7 +6,7 @@
 // stream is counter-based (Philox4x32-10, Salmon et al. SC'11) so that every (env, device, try) has its own
 // reproducible draw independent of launch geometry or sharding:
 //     counter = (global env index, device index, try, episode)      key = 64-bit seed
-//     word 0 -> theta = 2*pi*u, word 1 -> r = radius*sqrt(u),  u = (word >> 8) * 2^-24
+//     word 0 -> theta = 2*pi*u, u = (word >> 8) * 2^-24 in [0,1);  word 1 -> r = radius*sqrt(u), u = ((word >> 8) + 0.5) * 2^-24 in (0,1)
 // One thread per (env, device).  A DUE receiver thread re-derives its transmitter's position from the
 // transmitter's own counter instead of waiting for another thread, so there is no intra-kernel dependency.
 #include "d2d_internal.h"
@@ -27,8 +27,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 }
 
 __device__ __forceinline__ float2 disc_offset(unsigned w_theta, unsigned w_r, float radius) {
-    const float u1 = (float)(w_theta >> 8) * 5.9604644775390625e-08f;   // 2^-24, exact
-    const float u2 = (float)(w_r >> 8) * 5.9604644775390625e-08f;
+    const float u1 = (float)(w_theta >> 8) * 5.9604644775390625e-08f;   // [0, 1): 2^-24, exact
+    // radius draw on the OPEN interval (0, 1): u2 == 0 would put a CUE exactly on the base station or a DUE receiver
+    // exactly on its transmitter (distance 0 -> the step's log10(0) 'math domain error'); with [0, 1) that happens
+    // once per 2^24 draws, i.e. about every 8th reset of a 4096 x 512-device batch
+    const float u2 = ((float)(w_r >> 8) + 0.5f) * 5.9604644775390625e-08f;
     const float theta = 6.283185307179586f * u1;                        // position.py:24,41
     const float r = radius * sqrtf(u2);                                 // position.py:25,42
     float sn, cs;

@@ -1,5 +1,6 @@
 // Fused per-step kernel for gfx950 (MI355X): action decode -> received signal -> same-RB interference
-// reduction -> SINR / SNR / Shannon rate / capacity -> reward -> compact observation table.
+// reduction -> SINR / SNR / Shannon rate / capacity -> reward -> compact observation table (-> LinearObs expansion
+// in the same launch when N is small).
 //
 // Reference path being replaced (file:line under /root/reference/src/gym_d2d):
 //   D2DEnv._decode_action            envs/d2d_env.py:93-101
@@ -9,17 +10,25 @@
 //   Simulator._calculate_network_capacity  simulator.py:144-154
 //   Actions.get_actions_by_rb        actions.py:27-31
 //   {SystemCapacity,Shannon,CueSinrShannon}RewardFunction   envs/reward_fn.py:22-78
-//   LinearObsFunction._agent_obs     envs/obs_fn.py:55-61
+//   LinearObsFunction._agent_obs / get_state   envs/obs_fn.py:43-61
+//   UplinkTrafficModel / DownlinkTrafficModel  traffic_model.py:15-32 (links with fixed (rb, pwr) in their record)
 //
-// Design (one workgroup = one environment; environments are independent):
-//   * every link's transmitter tuple (tx_x, tx_y, effective tx power in mW, rb) is staged once in LDS as a
-//     float4, so the interference loop is one ds_read_b128 per candidate interferer;
-//   * same-RB interferers are found through per-RB membership bitmasks in LDS (R x ceil(N/64) u64 words,
-//     built with ds_or_b64 - order independent), walked in ascending link order with ctz; a masked
-//     all-pairs sweep is the fallback (rb outside [0,R), or mask table too large) and produces bit-identical
-//     sums because both walk interferers in ascending index order through the same fmaf;
-//   * all arithmetic is in the LINEAR domain (mW): sinr = S / (I + N) with one 10*log10 at the end; the
-//     literal dB-domain transcription cannot hold 1e-5 relative in fp32 (hard parts);
+// Design (environments are independent): a workgroup owns `epw` environments, `tpe` threads each
+// (thread = link); at N = 512 that is one env per 512-thread workgroup, at N = 50 several 64-thread envs share one.
+//   * every per-link input is ONE coalesced, independent load: the link's (tx_x, tx_y, rx_x, rx_y) row (built once per
+//     reset, launch_link_positions), its action, and three 16-byte rows of the host-built link record (L2-resident);
+//     10^(p/10) is computed (v_exp_f32 with an exact hi/lo exponent split), so nothing in the prologue is a dependent
+//     second hop;
+//   * every link's transmitter tuple (tx_x, tx_y, effective tx power in mW, rb | index) is staged in LDS as a float4,
+//     so the interference loop is one ds_read_b128 per candidate interferer;
+//   * same-RB interferers (Actions.get_actions_by_rb) are found through per-RB membership bitmasks in LDS (built with
+//     ds_or_b64 - order independent), then either walked directly in ascending link order with ctz
+//     (STEP_MASK_WALK), or used as the ranks of a STABLE counting sort by RB (popcount of the lower bits = rank in the
+//     bucket, wave scan of the per-RB counts = bucket start) so that a receiver streams one contiguous LDS segment
+//     (STEP_RB_SORTED).  A masked all-pairs sweep is the fallback (rb outside [0,R), or mask table too large).  All
+//     three visit interferers in ascending link index through the same fmaf, hence produce identical bits;
+//   * all arithmetic is in the LINEAR domain (mW): sinr = S / (I + N) with one 10*log10 at the end; the literal
+//     dB-domain transcription cannot hold 1e-5 relative in fp32 (hard parts);
 //   * reductions (capacity sum) are xor-butterfly wave reductions + a fixed-order cross-wave sum:
 //     run-to-run deterministic.
 #include "d2d_internal.h"
@@ -27,6 +36,8 @@
 namespace d2d {
 
 typedef unsigned long long u64;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define FLAG_ZERO_DISTANCE 1
 #define FLAG_RB_OOR 2
@@ -53,6 +64,16 @@ __device__ __forceinline__ float pow_neg_half(float d2, float e) {
     const float perr = fmaf(h, fe, -p);                     // exact residual of the product
     const float ip = rintf(p);
     const float fr = (p - ip) + fmaf(h, l, perr);
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(fr), (int)ip);
+}
+
+// 10^(p/10) for an integer power level p (dBm -> mW), ~1.5e-7 relative: 2^(p*c), c = log2(10)/10 split into a 12-bit
+// head (p*c_hi exact for |p| < 4096) and a tail, so only the fractional part of the exponent reaches v_exp_f32.
+__device__ __forceinline__ float pow10_tenth(int p) {
+    const float fp = (float)p;
+    const float xh = fp * 0.3321533203125f;                 // 2721 / 8192
+    const float ip = floorf(xh);
+    const float fr = (xh - ip) + fp * 3.948917623623e-05f;  // c - c_hi
     return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(fr), (int)ip);
 }
 
@@ -89,57 +110,85 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
     return exp2f(-0.33219280948873623f * a.shadow_chi * z);                     // 10^(-chi z / 10)
 }
 
-// LDS carve-up.  40 bytes per link + masks.
+// LDS carve-up of ONE env.  80 bytes + 40 bytes per link + masks (+ 24 bytes per link when the obs expansion is fused).
 struct Smem {
+    float* red;     // [16] wave partial sums of this env (first: 16-byte aligned for the float4 reads of the reduction)
+    int* flags;     // [4]  0: env flags  1: reward violated
     float4* link;   // [N] tx_x, tx_y, effective tx power (mW, incl. tx side of the PL constant), rb bits
+                    //     (STEP_RB_SORTED: in bucket order, .w = link index | link_type << 16)
     float2* rx;     // [N] rx_x, rx_y
     float* sinr;    // [N] sinr_db
     float* sh;      // [N] log2(1 + sinr_lin)
     float* expo;    // [N] path-loss exponent of the tx
     int* aux;       // [N] tx_dev | link_type << 24
-    float* red;     // [32]
-    int* flags;     // [4]  0: env flags  1: reward violated
+    float* tflat;   // [6N] obs base table of this env (fused expansion only)
     u64* mask;      // [W][R] per-RB membership (word-major: lanes with different RBs hit different banks), then [W] sidelink membership
-    unsigned* summ; // [R] bit w set <=> mask[rb][w] != 0: lets a receiver skip the empty words of its RB
+    unsigned* rbinfo; // [R] MASK_WALK: bit w set <=> mask[w][rb] != 0 (lets a receiver skip the empty words of its RB)
+                      //     RB_SORTED: member count, then bucket start | count << 16
 };
 
-__device__ __forceinline__ Smem carve(unsigned char* base, int N) {
+#define LDS_HEAD_BYTES 80        /* red[16] + flags[4] */
+#define LDS_TFLAT_OFFSET(N) (LDS_HEAD_BYTES + (size_t)(N) * 40)
+
+__host__ __device__ __forceinline__ size_t lds_fixed_bytes(int N, int fuse_obs) {
+    size_t bytes = LDS_TFLAT_OFFSET(N);
+    if (fuse_obs) bytes += (size_t)N * 24;
+    return (bytes + 7) & ~(size_t)7;
+}
+
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs) {
+    size_t bytes = lds_fixed_bytes(N, fuse_obs);
+    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words + (size_t)(R + 1) / 2) * 8;   // masks + per-RB words
+    return (bytes + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ size_t lds_env_bytes(int N, int R, int mask_words, int fuse_obs) {
+    size_t bytes = lds_fixed_bytes(N, fuse_obs);
+    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words + (size_t)(R + 1) / 2) * 8;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ Smem carve(unsigned char* base, int N, int R, int W, int fuse_obs) {
     Smem s;
-    s.link = reinterpret_cast<float4*>(base);
+    s.red = reinterpret_cast<float*>(base);
+    s.flags = reinterpret_cast<int*>(s.red + 16);
+    s.link = reinterpret_cast<float4*>(base + LDS_HEAD_BYTES);
     s.rx = reinterpret_cast<float2*>(s.link + N);
     s.sinr = reinterpret_cast<float*>(s.rx + N);
     s.sh = s.sinr + N;
     s.expo = s.sh + N;
     s.aux = reinterpret_cast<int*>(s.expo + N);
-    s.red = reinterpret_cast<float*>(s.aux + N);
-    s.flags = reinterpret_cast<int*>(s.red + 32);
-    s.mask = reinterpret_cast<u64*>(s.flags + 4);
+    s.tflat = reinterpret_cast<float*>(base + LDS_TFLAT_OFFSET(N));
+    s.mask = reinterpret_cast<u64*>(base + lds_fixed_bytes(N, fuse_obs));
+    s.rbinfo = reinterpret_cast<unsigned*>(s.mask + (size_t)R * W + W);
     return s;
-}
-
-size_t step_lds_bytes(int N, int R, int mask_words) {
-    size_t bytes = (size_t)N * 40 + 32 * 4 + 4 * 4;
-    bytes = (bytes + 7) & ~(size_t)7;
-    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words + (size_t)(R + 1) / 2) * 8;   // masks + summaries
-    return bytes;
 }
 
 // Everything pass 1 needs about one link, in registers.
 struct LinkIn {
-    int type, txd, rb, p;
-    float txx, txy, rxx, rxy, tx_lin, p10;
+    int type, txd, rxd, rb, p;
+    float4 pos;          // tx_x, tx_y, rx_x, rx_y
+    float4 rb_;          // rec_b: tx_lin, rx_pl, rx_lin, noise_mw
+    float4 rc;           // rec_c: sens_db, bw_mhz, exponent
 };
 
-__device__ __forceinline__ LinkIn load_link(const StepArgs& a, const float* px, const float* py, size_t row, int i) {
+// All five loads are independent of one another (no link -> device -> position double hop, no power-table lookup).
+__device__ __forceinline__ LinkIn load_link(const StepArgs& a, size_t row, size_t act_row, int i) {
     LinkIn in;
-    // hop 1: link table, per-link constant, action
-    in.type = a.link_type[i];
-    in.txd = a.link_tx[i];
-    const int rxd = a.link_rx[i];
-    in.tx_lin = a.lk_tx_lin[i];
-    if (a.action_mode == 0) {
+    const int4 ra = a.rec_a[i];
+    in.rb_ = a.rec_b[i];
+    in.rc = a.rec_c[i];
+    in.pos = a.lpos[row + i];
+    in.type = (ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
+    in.txd = ra.x & D2D_REC_TXDEV_MASK;
+    in.rxd = ra.y;
+    if (ra.x & D2D_REC_FIXED_BIT) {
+        // a link driven by the traffic model (traffic_model.py:15-32): (rb, pwr) live in the record, agents do not
+        // supply an action for it.  No decode: any power is legal, as in the reference's Action(rb, pwr).
+        in.rb = ra.z; in.p = ra.w;
+    } else if (a.action_mode == 0) {
         // d2d_env.py:94-96 with Python floor semantics; NB due_min_tx_power_dBm is not added back
-        const int act = a.actions[row + i];
+        const int act = a.actions[act_row + ra.z];
         const int P = in.type == LINK_SIDELINK ? a.p_due : (in.type == LINK_UPLINK ? a.p_cue : a.p_mbs);
         int q, r;
         if (act >= 0) {
@@ -155,71 +204,117 @@ __device__ __forceinline__ LinkIn load_link(const StepArgs& a, const float* px, 
     } else {
         in.rb = a.rb_in[row + i]; in.p = a.pwr_in[row + i];
     }
-    // hop 2: positions of the two devices, 10^(p/10) for the integer power level
-    in.txx = px[in.txd]; in.txy = py[in.txd];
-    in.rxx = px[rxd]; in.rxy = py[rxd];
-    in.p10 = (unsigned)in.p < 128u ? a.pow10_tab[in.p] : exp10f(0.1f * (float)in.p);
     return in;
 }
 
-// SINGLE = every thread owns at most one link (N <= blockDim, the normal case up to 1024 links): the per-link loops
-// collapse to a single predicated body, which removes their exec-mask bookkeeping from the scalar pipe.
-#define FOR_MY_LINKS(i) for (int i = tid, go_ = 1; go_ && i < N; i += T, go_ = !SINGLE)
+// source float index inside T_flat for output column f (even) of row i (obs_fn.py:43-53: own link first, then the
+// others in agent order)
+__device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
+    const unsigned head = 6u * i;
+    return f < 6u ? head + f : (f < head + 6u ? f - 6u : f);
+}
 
-template <int MODE, bool SINGLE>
+// SINGLE = every thread owns at most one link (N <= tpe, the normal case up to 1024 links): the per-link loops
+// collapse to a single predicated body, which removes their exec-mask bookkeeping from the scalar pipe.
+#define FOR_MY_LINKS(i) for (int i = lt, go_ = 1; go_ && active && i < N; i += TPE, go_ = !SINGLE)
+
+template <int MODE, bool SINGLE, bool SORTED>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int N = a.N, R = a.R, D = a.D, W = a.mask_words;
-    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int N = a.N, R = a.R, D = a.D, W = a.mask_words, TPE = a.tpe;
+    const int tid = threadIdx.x;
+    const int e = tid / TPE, lt = tid - e * TPE;          // env slot in this workgroup (wave-uniform: TPE % 64 == 0)
+    const int b = blockIdx.x * a.epw + e;
+    const bool active = e < a.epw && b < a.B;
     const size_t row = (size_t)b * N;
-    Smem s = carve(smem_raw, N);
-    // carve() aligns the mask region to 8 bytes the same way step_lds_bytes does
-    s.mask = reinterpret_cast<u64*>((reinterpret_cast<uintptr_t>(s.flags + 4) + 7) & ~(uintptr_t)7);
-    s.summ = reinterpret_cast<unsigned*>(s.mask + (size_t)R * W + W);
+    const size_t act_row = (size_t)b * a.act_stride;
+    const size_t env_lds = lds_env_bytes(N, R, W, a.fuse_obs);
+    Smem s = carve(smem_raw + (size_t)(e < a.epw ? e : 0) * env_lds, N, R, W, a.fuse_obs);
 
-    // ---- prologue: issue this thread's first link's loads BEFORE any LDS work or barrier, so their latency (the
-    // link table / action hop, then the dependent position / 10^(p/10) hop) overlaps pass 0 and the barrier.
-    // Per-link constants are host-flattened arrays (lk_*[N], d2d_capi.hip refresh_tables), so there is no
-    // link -> device -> column double hop in the kernel.
-    const float* px = a.pos_x + (size_t)b * D;
-    const float* py = a.pos_y + (size_t)b * D;
+    // ---- prologue: issue this thread's link's loads BEFORE any LDS work or barrier, so their latency overlaps pass 0
     LinkIn first;
-    if (tid < N) first = load_link(a, px, py, row, tid);
+    if (active && lt < N) first = load_link(a, row, act_row, lt);
 
     // ---- pass 0: clear masks and flags
     const bool want_masks = W > 0;
-    if (want_masks)
-        for (int k = tid; k < R * W + W + (R + 1) / 2; k += T) s.mask[k] = 0ull;      // masks + summary words
-    if (tid < 4) s.flags[tid] = 0;
-    if (tid < 32) s.red[tid] = 0.0f;
+    if (active) {
+        if (want_masks)
+            for (int k = lt; k < R * W + W + (R + 1) / 2; k += TPE) s.mask[k] = 0ull;      // masks + per-RB words
+        if (lt < 4) s.flags[lt] = 0;
+        if (lt < 16) s.red[lt] = 0.0f;
+    }
     __syncthreads();
 
     // ---- pass 1: decode + stage the transmitter side of every link
     float4 me0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 rx0 = make_float2(0.f, 0.f);
     FOR_MY_LINKS(i) {
-        const LinkIn in = i == tid ? first : load_link(a, px, py, row, i);
-        const int type = in.type, txd = in.txd;
-        const int rb = in.rb, p = in.p;
-        const float4 tuple = make_float4(in.txx, in.txy, in.p10 * in.tx_lin, __int_as_float(rb));
-        s.link[i] = tuple;
-        s.rx[i] = make_float2(in.rxx, in.rxy);
-        s.aux[i] = txd | (type << 24);
-        if (i == tid) { me0 = tuple; rx0 = make_float2(in.rxx, in.rxy); }   // own link stays in registers for pass 2
-        if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = a.lk_exp[i];
-        if (a.rb_out) { a.rb_out[row + i] = rb; a.pwr_out[row + i] = p; }
+        const LinkIn in = i == lt ? first : load_link(a, row, act_row, i);
+        const int rb = in.rb;
+        const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(in.p) * in.rb_.x, __int_as_float(rb));
+        if (!SORTED) s.link[i] = tuple;
+        s.rx[i] = make_float2(in.pos.z, in.pos.w);
+        s.aux[i] = in.txd | (in.type << 24);
+        if (i == lt) me0 = tuple;                                        // own link stays in registers for pass 2
+        if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
+        if (a.rb_out) { a.rb_out[row + i] = rb; a.pwr_out[row + i] = in.p; }
         if (want_masks) {
             const u64 bit = 1ull << (i & 63);
             if ((unsigned)rb < (unsigned)R) {
                 atomicOr(&s.mask[(size_t)(i >> 6) * R + rb], bit);
-                atomicOr(&s.summ[rb], 1u << (i >> 6));
+                if (SORTED) atomicAdd(&s.rbinfo[rb], 1u);
+                else atomicOr(&s.rbinfo[rb], 1u << (i >> 6));
             }
             else atomicOr(&s.flags[0], FLAG_RB_OOR);
-            if (type == LINK_SIDELINK) atomicOr(&s.mask[(size_t)R * W + (i >> 6)], bit);
+            if (in.type == LINK_SIDELINK) atomicOr(&s.mask[(size_t)R * W + (i >> 6)], bit);
         }
     }
     __syncthreads();
-    const bool use_masks = want_masks && !(s.flags[0] & FLAG_RB_OOR);
+    const bool use_masks = want_masks && active && !(s.flags[0] & FLAG_RB_OOR);
+
+    // ---- pass 1b (STEP_RB_SORTED): stable counting sort of the transmitter tuples by RB.
+    //   rank of link i inside its bucket = number of lower-indexed members = popcount of the mask bits below i;
+    //   bucket starts = exclusive scan of the member counts (one wave per env, K consecutive RBs per lane).
+    // Ascending link order inside a bucket is what keeps the interference sum bit-identical to the other variants.
+    int my_rank = 0;
+    if (SORTED) {
+        if (use_masks && lt < N) {
+            const int rb = __float_as_int(me0.w);
+            const int wi = lt >> 6;
+            for (int w = 0; w < wi; ++w) my_rank += __popcll(s.mask[(size_t)w * R + rb]);
+            my_rank += __popcll(s.mask[(size_t)wi * R + rb] & ((1ull << (lt & 63)) - 1ull));
+        }
+        if (use_masks && lt < 64) {
+            const int K = (R + 63) >> 6;
+            const int r0 = lt * K;
+            unsigned local = 0;
+            for (int k = 0; k < K; ++k) local += (r0 + k < R) ? s.rbinfo[r0 + k] : 0u;
+            unsigned incl = local;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o);
+                if (lt >= o) incl += t;
+            }
+            unsigned start = incl - local;
+            for (int k = 0; k < K; ++k)
+                if (r0 + k < R) {
+                    const unsigned c = s.rbinfo[r0 + k];
+                    s.rbinfo[r0 + k] = start | (c << 16);
+                    start += c;
+                }
+        }
+        __syncthreads();
+        if (active && lt < N) {
+            if (use_masks) {
+                const unsigned se = s.rbinfo[__float_as_int(me0.w)];
+                s.link[(se & 0xFFFFu) + my_rank] =
+                    make_float4(me0.x, me0.y, me0.z, __int_as_float(lt | (first.type << 16)));
+            } else {
+                s.link[lt] = me0;                                        // all-pairs fallback: by link index, .w = rb
+            }
+        }
+        __syncthreads();
+    }
+
     const float* gtab = MODE == PL_TABLE ? a.gain_table + (size_t)b * a.table_env_stride : nullptr;
     const unsigned genv = (unsigned)(a.env_offset + (unsigned long long)b);   // global env index (RNG counter)
 
@@ -228,20 +323,40 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     int my_flags = 0;
     bool violated = false;
     FOR_MY_LINKS(i) {
-        const float4 me = i == tid ? me0 : s.link[i];
-        const float2 rx = i == tid ? rx0 : s.rx[i];
-        const int rb = __float_as_int(me.w);
-        const int txd = i == tid ? first.txd : (s.aux[i] & 0xFFFFFF);
-        const int rxd = a.link_rx[i];
-        // per-link receiver / transmitter constants: coalesced, issued ahead of the mask walk that hides them
-        const float rx_pl = a.lk_rx_pl[i], rx_lin = a.lk_rx_lin[i], noise = a.lk_noise_mw[i];
-        const float sens = a.lk_sens_db[i], bw_mhz = a.lk_bw_mhz[i];
+        const LinkIn in = i == lt ? first : load_link(a, row, act_row, i);   // strided links: records re-read (L2)
+        const float4 me = i == lt ? me0 : s.link[i];
+        const float2 rx = make_float2(in.pos.z, in.pos.w);
+        const int rb = i == lt ? __float_as_int(me0.w) : in.rb;
+        const int txd = in.txd, rxd = in.rxd;
+        const float rx_pl = in.rb_.y, rx_lin = in.rb_.z, noise = in.rb_.w;
+        const float sens = in.rc.x, bw_mhz = in.rc.y;
         float acc = 0.0f;
         bool zero = false;
 
-        if (use_masks) {
+        if (SORTED && use_masks) {
+            const unsigned se = s.rbinfo[rb];
+            const int st = (int)(se & 0xFFFFu), cnt = (int)(se >> 16);       // cnt >= 1: this link itself
+            for (int k0 = 0; k0 < cnt; k0 += 4) {
+                float4 o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = s.link[st + min(k0 + u, cnt - 1)];   // 4 independent reads in flight
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u;
+                    const bool use = (k < cnt) & (k != my_rank);                    // .difference({action}), simulator.py:95
+                    const int j = __float_as_int(o[u].w) & 0xFFFF;
+                    const float dx = o[u].x - rx.x, dy = o[u].y - rx.y;
+                    const float d2 = fmaf(dx, dx, dy * dy);
+                    float g;
+                    if (MODE == PL_TABLE) g = use ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
+                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); zero |= use & (d2 == 0.0f); }
+                    if (MODE == PL_SHADOW && use && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
+                    acc = use ? fmaf(o[u].z, g, acc) : acc;                         // simulator.py:97-101, linear mW
+                }
+            }
+        } else if (use_masks) {
             const u64* m = s.mask + rb;                                   // word w of this RB: m[w * R]
-            unsigned live = s.summ[rb];                                   // non-empty words of this RB, ascending
+            unsigned live = s.rbinfo[rb];                                 // non-empty words of this RB, ascending
             while (live) {
                 const int w = __builtin_ctz(live);
                 live &= live - 1;
@@ -280,7 +395,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
-        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[i] : 2.0f); zero |= d2 == 0.0f; }
+        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); zero |= d2 == 0.0f; }
         float sig = me.z * g * rx_pl * rx_lin;                           // mW at the receiver, with rx gains
         float sig_snr = sig;
         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
@@ -311,22 +426,23 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             t[1] = rx;
             t[2] = make_float2(sinr_db, snr_db);
         }
-        // staged only for the reward pass that reads them (reward_fn.py): 1 -> cap; 2 -> own sinr, sh; 3 -> sinr, sh
-        if (a.reward_fn >= 2) { s.sinr[i] = sinr_db; s.sh[i] = sh; }    // staged for reward passes 2 / 3 only
+        if (a.fuse_obs) {
+            float2* t = reinterpret_cast<float2*>(s.tflat + 6 * i);
+            t[0] = make_float2(me.x, me.y);
+            t[1] = rx;
+            t[2] = make_float2(sinr_db, snr_db);
+        }
+        // staged only for the reward pass that reads them (reward_fn.py): 2 -> own sinr, sh; 3 -> sinr, sh
+        if (a.reward_fn >= 2) { s.sinr[i] = sinr_db; s.sh[i] = sh; }
         if (a.reward_fn == 1) {
             // SystemCapacityRewardFunction's -1 rule (reward_fn.py:29-41), from this link's side: I am a non-D2D
             // link whose capacity is <= min_capacity and some D2D link shares my RB.  Masks / tuples of ALL links
             // were published by the barrier before this pass, so no further synchronisation is needed here.
-            const int type_i = i == tid ? first.type : (s.aux[i] >> 24);
-            if (type_i != LINK_SIDELINK && cap <= a.reward_param) {
+            if (in.type != LINK_SIDELINK && cap <= a.reward_param) {
                 bool hit = false;
                 if (use_masks) {
-                    unsigned live = s.summ[rb];
-                    while (live) {
-                        const int w = __builtin_ctz(live);
-                        live &= live - 1;
+                    for (int w = 0; w < W; ++w)
                         hit |= (s.mask[(size_t)w * R + rb] & s.mask[(size_t)R * W + w]) != 0ull;
-                    }
                 } else {
                     for (int k = 0; k < N; ++k)
                         hit |= (k != i) & ((s.aux[k] >> 24) == LINK_SIDELINK) & (__float_as_int(s.link[k].w) == rb);
@@ -345,15 +461,16 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone if any link reported
         // a violation above.  One barrier: wave partial sums + the violation flag.
         const float wsum = wave_sum(cap_part);
-        if ((tid & 63) == 0) s.red[tid >> 6] = wsum;
+        if (active && (lt & 63) == 0) s.red[lt >> 6] = wsum;
         if (violated) atomicOr(&s.flags[1], 1);
         __syncthreads();
-        float total = 0.0f;
-        const int nw = (T + 63) >> 6;
-        const float4* red4 = reinterpret_cast<const float4*>(s.red);       // 16 slots, zero-padded: fixed-order sum
-        for (int w = 0; w < (nw + 3) >> 2; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
-        const float r = s.flags[1] ? -1.0f : total / (float)N;
-        FOR_MY_LINKS(i) a.reward[row + i] = r;
+        if (active) {
+            const float4* red4 = reinterpret_cast<const float4*>(s.red);       // 16 slots, zero-padded: fixed-order sum
+            float total = 0.0f;
+            for (int w = 0; w < (TPE + 255) >> 8; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
+            const float r = s.flags[1] ? -1.0f : total / (float)N;
+            FOR_MY_LINKS(i) a.reward[row + i] = r;
+        }
     } else if (a.reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57
         FOR_MY_LINKS(i) a.reward[row + i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
@@ -362,10 +479,17 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         // CueSinrShannonRewardFunction, reward_fn.py:65-78
         __syncthreads();
         FOR_MY_LINKS(i) {
-            const int rbi = __float_as_int(s.link[i].w);
+            const int rbi = i == lt ? __float_as_int(me0.w) : load_link(a, row, act_row, i).rb;
             bool bad = false;
-            if (use_masks) {
-                unsigned live = s.summ[rbi];
+            if (SORTED && use_masks) {
+                const unsigned se = s.rbinfo[rbi];
+                const int st = (int)(se & 0xFFFFu), cnt = (int)(se >> 16);
+                for (int k = 0; k < cnt; ++k) {
+                    const int wj = __float_as_int(s.link[st + k].w);
+                    bad |= (k != my_rank) & ((wj >> 16) != LINK_SIDELINK) & (s.sinr[wj & 0xFFFF] < a.reward_param);
+                }
+            } else if (use_masks) {
+                unsigned live = s.rbinfo[rbi];
                 while (live) {
                     const int w = __builtin_ctz(live);
                     live &= live - 1;
@@ -389,7 +513,37 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         __syncthreads();
     }
 
-    if (tid == 0) a.env_flags[b] = s.flags[0];
+    if (active && lt == 0) a.env_flags[b] = s.flags[0];
+
+    // ---- pass 4 (small N only): LinearObs expansion of this workgroup's envs, obs_fn.py:43-53.  Every thread of the
+    // workgroup streams 16-byte (or 8-byte, odd N) stores over the contiguous [N][6N] block of each env; tflat was
+    // published by the reward pass's barrier.  Same mapping as csrc/d2d_obs.hip (bit-identical output).
+    if (a.fuse_obs) {
+        const unsigned T = blockDim.x, q_per_row = a.obs_q_per_row, total = (unsigned)N * q_per_row;
+        const unsigned row_floats = 6u * (unsigned)N;
+        for (int el = 0; el < a.epw; ++el) {
+            const int be = blockIdx.x * a.epw + el;
+            if (be >= a.B) break;
+            const float* t_flat = reinterpret_cast<const float*>(
+                smem_raw + (size_t)el * env_lds + LDS_TFLAT_OFFSET(N));
+            float* out = a.obs + (size_t)be * N * row_floats;
+#pragma unroll 2
+            for (unsigned idx = tid; idx < total; idx += T) {
+                const unsigned i = (unsigned)(((unsigned long long)idx * a.obs_q_magic) >> 40);   // idx / q_per_row
+                const unsigned q = idx - i * q_per_row;
+                if (a.fuse_obs == 4) {
+                    const unsigned f = q * 4u;
+                    const f32x2 lo = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(f, i) >> 1];
+                    const f32x2 hi = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(f + 2u, i) >> 1];
+                    const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)idx * 4));
+                } else {
+                    const f32x2 v = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(q * 2u, i) >> 1];
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(out + (size_t)idx * 2));
+                }
+            }
+        }
+    }
 }
 
 // OR-reduction of the per-env flag words, run only when the host asks (d2d_status_flags): keeps the memset +
@@ -411,27 +565,51 @@ hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_step(const StepArgs& a, PlMode mode, hipStream_t stream) {
-    int threads = a.threads > 0 ? a.threads : ((a.N + 63) / 64) * 64;
-    if (threads > 1024) threads = 1024;
-    if (threads < 64) threads = 64;
-    const size_t lds = step_lds_bytes(a.N, a.R, a.mask_words);
-    dim3 grid(a.B), block(threads);
+// Per-link position rows (tx_x, tx_y, rx_x, rx_y): the link -> device gather done ONCE per reset / link change
+// (simulator.py:61-75 only moves devices in reset()), so that the step kernel's prologue is a single coalesced 16-byte
+// load per link instead of a dependent link table -> device position double hop.
+__global__ __launch_bounds__(256) void link_positions_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                            const int4* __restrict__ rec_a, int B, int N, int D,
+                                                            float4* __restrict__ lpos) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)B * N) return;
+    const int b = (int)(gid / N), i = (int)(gid - (size_t)b * N);
+    const int4 ra = rec_a[i];
+    const size_t base = (size_t)b * D;
+    const int txd = ra.x & D2D_REC_TXDEV_MASK, rxd = ra.y;
+    lpos[gid] = make_float4(px[base + txd], py[base + txd], px[base + rxd], py[base + rxd]);
+}
+
+hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const int4* rec_a, int B, int N, int D,
+                                 float4* lpos, hipStream_t stream) {
+    const size_t total = (size_t)B * N;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(link_positions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pos_x, pos_y,
+                       rec_a, B, N, D, lpos);
+    return hipGetLastError();
+}
+
+hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream) {
+    const size_t lds = step_lds_bytes_per_env(a.N, a.R, a.mask_words, a.fuse_obs) * (size_t)a.epw;
+    dim3 grid((unsigned)((a.B + a.epw - 1) / a.epw)), block(block_threads);
     hipError_t err = hipSuccess;
-    const bool single = a.N <= threads;
-#define D2D_LAUNCH_1(M, S)                                                                               \
+    const bool single = a.N <= a.tpe;
+    const bool sorted = a.variant == STEP_RB_SORTED && single && a.mask_words > 0;
+#define D2D_LAUNCH_1(M, S, Q)                                                                            \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M, S>),                 \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M, S, Q>),              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         if (err == hipSuccess) {                                                                         \
-            hipLaunchKernelGGL((step_kernel<M, S>), grid, block, lds, stream, a);                        \
+            hipLaunchKernelGGL((step_kernel<M, S, Q>), grid, block, lds, stream, a);                     \
             err = hipGetLastError();                                                                     \
         }                                                                                                \
     } while (0)
 #define D2D_LAUNCH(M)                                                                                    \
     do {                                                                                                 \
-        if (single) D2D_LAUNCH_1(M, true); else D2D_LAUNCH_1(M, false);                                  \
+        if (sorted) D2D_LAUNCH_1(M, true, true);                                                         \
+        else if (single) D2D_LAUNCH_1(M, true, false);                                                   \
+        else D2D_LAUNCH_1(M, false, false);                                                              \
     } while (0)
     switch (mode) {
         case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;

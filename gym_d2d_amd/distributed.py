@@ -40,14 +40,37 @@ class StepGatherer:
         g.launch(reward, table)                # after every step: rewards + (sinr, snr), asynchronous
         rewards, signal = g.wait()             # [B_global], [B_global, N, 2]
         table = g.table()                      # [B_global, N, 6] assembled on demand
+
+    backend 'torch' (default): torch.distributed collectives ("nccl" = RCCL on ROCm, "gloo" on CPU).
+    backend 'native': the library's own RCCL entry (d2d_comm_init / d2d_allgather, include/d2d_hip.h) on `handle`;
+    torch.distributed is then only used once, to ship rank 0's 128-byte unique id to the other ranks.
     """
 
-    def __init__(self, b_local: int, n_links: int, device: torch.device, group=None) -> None:
+    def __init__(self, b_local: int, n_links: int, device: torch.device, group=None, *, backend: str = 'torch',
+                 handle=None) -> None:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device
         self.cuda = device.type == 'cuda'
+        # all_gather_into_tensor needs the same shard size on every rank (shard_range may hand out uneven shards):
+        # fail here with a clear message instead of hanging / corrupting inside the collective
+        sizes = torch.tensor([b_local, -b_local], dtype=torch.int64, device=device)
+        dist.all_reduce(sizes, op=dist.ReduceOp.MIN, group=group)
+        lo, hi = int(sizes[0].item()), -int(sizes[1].item())
+        if lo != hi:
+            raise ValueError(f'StepGatherer needs equal shards on every rank, got between {lo} and {hi} envs per rank; '
+                             'pad the batch to a multiple of the world size')
+        if backend not in ('torch', 'native'):
+            raise ValueError("backend must be 'torch' or 'native'")
+        self.backend = backend
+        self.handle = handle
+        if backend == 'native':
+            if handle is None or not self.cuda:
+                raise ValueError("backend='native' needs the env's native handle and a CUDA device")
+            box = [handle.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            handle.comm_init(self.world, self.rank, box[0])
         f32 = torch.float32
         self.stage_reward = torch.empty(b_local, dtype=f32, device=device)
         self.stage_signal = torch.empty((b_local, n_links, 2), dtype=f32, device=device)
@@ -60,10 +83,19 @@ class StepGatherer:
             self.done = torch.cuda.Event()
         self._pending = False
 
+    def _all_gather(self, out: torch.Tensor, local: torch.Tensor, stream_ptr: int = 0) -> None:
+        if self.backend == 'native':
+            self.handle.allgather(local.data_ptr(), out.data_ptr(), local.numel() * local.element_size(), stream_ptr)
+        else:
+            dist.all_gather_into_tensor(out, local, group=self.group)
+
     def gather_positions(self, table: torch.Tensor) -> torch.Tensor:
         """Once per episode: all ranks' (tx_x, tx_y, rx_x, rx_y) columns of T -> [B_global, N, 4]."""
         local = table[:, :, :4].contiguous()
-        dist.all_gather_into_tensor(self.all_positions, local, group=self.group)
+        if self.backend == 'native':
+            self._all_gather(self.all_positions, local, torch.cuda.current_stream(self.device).cuda_stream)
+        else:
+            self._all_gather(self.all_positions, local)
         return self.all_positions
 
     def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor) -> None:
@@ -76,15 +108,15 @@ class StepGatherer:
                 self.stage_reward.copy_(reward_per_agent[:, 0])
                 self.stage_signal.copy_(table[:, :, 4:6])
                 self.staged.record(self.comm_stream)
-                dist.all_gather_into_tensor(self.all_reward, self.stage_reward, group=self.group)
-                dist.all_gather_into_tensor(self.all_signal, self.stage_signal, group=self.group)
+                self._all_gather(self.all_reward, self.stage_reward, self.comm_stream.cuda_stream)
+                self._all_gather(self.all_signal, self.stage_signal, self.comm_stream.cuda_stream)
                 self.done.record(self.comm_stream)
             cur.wait_event(self.staged)                         # next step may overwrite table/reward now
         else:
             self.stage_reward.copy_(reward_per_agent[:, 0])
             self.stage_signal.copy_(table[:, :, 4:6])
-            dist.all_gather_into_tensor(self.all_reward, self.stage_reward, group=self.group)
-            dist.all_gather_into_tensor(self.all_signal, self.stage_signal, group=self.group)
+            self._all_gather(self.all_reward, self.stage_reward)
+            self._all_gather(self.all_signal, self.stage_signal)
         self._pending = True
 
     def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -101,9 +133,29 @@ class StepGatherer:
         return torch.cat([self.all_positions, signal], dim=2)
 
 
-def expand_table(table: torch.Tensor) -> torch.Tensor:
-    """Consumer-side LinearObs expansion of a gathered table [B, N, 6] -> [B, N, 6N] with torch ops (what a learner on
-    another GPU does instead of receiving the expanded tensor).  obs[b,i] = (T[i], T[0..i-1], T[i+1..])."""
+def expand_table(table: torch.Tensor, handle=None, out: torch.Tensor = None) -> torch.Tensor:
+    """Consumer-side LinearObs expansion of a gathered table [B, N, 6] -> [B, N, 6N] (what a learner on another GPU
+    does instead of receiving the expanded tensor).  obs[b,i] = (T[i], T[0..i-1], T[i+1..]) (obs_fn.py:43-53).
+
+    CUDA tensors run the library's own expansion kernel through d2d_expand_table on `handle` (any native handle on
+    that GPU; bit-identical to the D2D_BUF_OBS the owning rank produced) on torch's current stream.  CPU tensors -
+    the gloo tests - use torch indexing."""
+    b, n, w = table.shape
+    if table.is_cuda:
+        if handle is None:
+            raise ValueError('expand_table on a CUDA tensor needs a native handle (d2d_expand_table); there is no '
+                             'generic-torch fallback on the GPU')
+        table = table.contiguous()
+        if out is None:
+            out = torch.empty((b, n, n * w), dtype=torch.float32, device=table.device)
+        handle.set_stream(torch.cuda.current_stream(table.device).cuda_stream)
+        handle.expand_table(table.data_ptr(), b, n, out.data_ptr())
+        return out
+    return expand_table_torch(table)
+
+
+def expand_table_torch(table: torch.Tensor) -> torch.Tensor:
+    """The same expansion with torch advanced indexing (CPU tensors; reference for the kernel in the tests)."""
     b, n, w = table.shape
     idx = torch.arange(n, device=table.device)
     k = torch.arange(n, device=table.device)

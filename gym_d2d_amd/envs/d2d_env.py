@@ -106,14 +106,13 @@ class D2DEnv(Env):
 
     # ------------------------------------------------------------------ internals
     def _run(self, actions: Actions) -> NativeState:
-        state = self.simulator.step(actions)
-        sim = self.simulator
-        if self._native_obs:
-            state.linear_obs = sim.fetch(_native.BUF_OBS, 0, 1)[0].astype(np.float64)
-        state.obs_table = sim.fetch(_native.BUF_OBS_TABLE, 0, 1)[0].astype(np.float64)
+        state = self.simulator.step(actions)          # every result of the step arrives in one packed host block
+        if not self._native_obs:
+            state.linear_obs = None
         if self._native_reward:
-            state.native_reward = sim.fetch(_native.BUF_REWARD, 0, 1)[0].astype(np.float64)
             state.native_reward_key = self._reward_key
+        else:
+            state.native_reward = None
         return state
 
     def _reset_random_actions(self) -> Actions:

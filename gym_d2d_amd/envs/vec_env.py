@@ -22,6 +22,7 @@ import numpy as np
 from .. import _native
 from ..simulator import BASE_STATION_ID, Simulator
 from ..traffic_model import DownlinkTrafficModel
+from . import _rng
 from .d2d_env import EPISODE_LENGTH
 from .obs_fn import ArrayObsFunction, LinearObsFunction, ObsFunction
 from .reward_fn import SystemCapacityRewardFunction
@@ -40,8 +41,15 @@ class VecD2DEnv:
                  cue_actions: str = 'agent', use_torch: Optional[bool] = None, first_env: int = 0) -> None:
         """cue_actions: 'agent' - step() takes actions for CUEs and DUEs [B, C+P] (reference behaviour);
         'traffic' - CUE links follow the env's traffic model (round-robin RB at max power,
-        traffic_model.py:15-22) and step() takes DUE actions only [B, P].
-        first_env: global index of env 0 when one logical batch is sharded over several GPUs."""
+        traffic_model.py:15-22): their (rb, pwr) are constants of the kernel's link records
+        (d2d_set_fixed_actions) and step() takes DUE actions only [B, P] - the CUE half of the action
+        traffic does not exist.
+        first_env: global index of env 0 when one logical batch is sharded over several GPUs (positions AND the
+        random actions of reset() are keyed by global env index, so a sharded run reproduces the single-GPU run).
+
+        reset() checks the status flags once and raises ValueError('math domain error') if two interacting devices
+        coincide (what the reference's log10(0) does, path_loss.py:66); step() does not synchronise - poll
+        status_flags() for FLAG_ZERO_DISTANCE / FLAG_NON_FINITE if positions are written from outside."""
         env_config = dict(env_config or {})
         obs_cls = env_config.pop('obs_fn', LinearObsFunction)
         rew_cls = env_config.pop('reward_fn', SystemCapacityRewardFunction)
@@ -79,6 +87,12 @@ class VecD2DEnv:
         self.num_agents = self.num_links if cue_actions == 'agent' else self.num_due_pairs
 
         h = sim.handle
+        self.first_env = int(first_env)
+        if cue_actions == 'traffic' and self.num_cues:
+            # (rb, pwr) exactly as TrafficModel.get_traffic would hand them to the simulator: no a // P encode /
+            # decode round trip, so a device_config_file max_tx_power_dBm above the action alphabet stays legal
+            rb, pwr = sim.traffic_model.assignments(sim.devices)
+            h.set_fixed_actions(np.arange(self.num_cues), rb, pwr)
         h.set_env_offset(first_env)
         h.set_obs_mode(self.obs_fn.native_mode)
         h.set_reward(rid, float(getattr(self.reward_fn, 'native_param', 0.0)))
@@ -89,9 +103,6 @@ class VecD2DEnv:
         self.num_steps = 0
         self._episode = 0
         self._seed = cfg.seed if cfg.seed is not None else 0
-        if cue_actions == 'traffic':
-            rb, pwr = sim.traffic_model.assignments(sim.devices)
-            self._cue_raw = (rb.astype(np.int64) * self.num_pwr_actions[self._cue_kind] + pwr).astype(np.int32)
 
     # ------------------------------------------------------------------ buffers
     def _bind_torch_buffers(self) -> None:
@@ -109,7 +120,8 @@ class VecD2DEnv:
 
         self._t['pos_x'] = alloc(_native.BUF_POS_X, (b, d), torch.float32)
         self._t['pos_y'] = alloc(_native.BUF_POS_Y, (b, d), torch.float32)
-        for name, which in (('actions', _native.BUF_ACTIONS), ('rb', _native.BUF_RB), ('pwr', _native.BUF_PWR)):
+        self._t['actions'] = alloc(_native.BUF_ACTIONS, (b * cap,), torch.int32)[:b * self.num_agents].view(b, self.num_agents)
+        for name, which in (('rb', _native.BUF_RB), ('pwr', _native.BUF_PWR)):
             self._t[name] = alloc(which, (b * cap,), torch.int32)[:b * n].view(b, n)
         for name, which in _OUTPUTS:
             self._t[name] = alloc(which, (b * cap,), torch.float32)[:b * n].view(b, n)
@@ -144,60 +156,55 @@ class VecD2DEnv:
         return SimpleNamespace(**v)
 
     # ------------------------------------------------------------------ gym-like API
+    def _initial_action_highs(self):
+        n_cue = self.config.num_rbs * self.num_pwr_actions[self._cue_kind]
+        n_due = self.config.num_rbs * self.num_pwr_actions['due']
+        return ([n_cue] * self.num_cues if self.cue_actions == 'agent' else []) + [n_due] * self.num_due_pairs
+
     def reset(self, seed: Optional[int] = None):
         """New positions for every env (device-side sampler), then one step with uniformly random actions on every
-        CUE uplink and DUE sidelink to produce the initial SINRs (d2d_env.py:45-60)."""
+        agent-driven link to produce the initial SINRs (d2d_env.py:45-60).  Both draws are counter-based and keyed
+        by global env index (first_env + b)."""
         if seed is not None:
             self._seed, self._episode = int(seed), 0
         self.num_steps = 0
         if self.use_torch:
             self._follow_torch_stream()
         self.simulator.reset_device(self._seed, self._episode)
-        self._episode += 1
-        n_cue = self.config.num_rbs * self.num_pwr_actions['cue']
-        n_due = self.config.num_rbs * self.num_pwr_actions['due']
+        highs = self._initial_action_highs()
         if self.use_torch:
-            g = torch.Generator(device=self.device)
-            g.manual_seed((self._seed * 1000003 + self._episode) & 0x7FFFFFFFFFFF)
-            a = self._t['actions']
-            if self.num_cues and self.cue_actions == 'traffic':
-                a[:, :self.num_cues] = self._cue_raw_tensor()           # CUE links always follow the traffic model
-            elif self.num_cues:
-                a[:, :self.num_cues] = torch.randint(0, n_cue, (self.num_envs, self.num_cues), generator=g,
-                                                     device=self.device, dtype=torch.int32)
-            if self.num_due_pairs:
-                a[:, self.num_cues:] = torch.randint(0, n_due, (self.num_envs, self.num_due_pairs), generator=g,
-                                                     device=self.device, dtype=torch.int32)
+            if self.num_agents:
+                self._t['actions'].copy_(_rng.uniform_ints_torch(torch, self._seed, self._episode, self.first_env,
+                                                                  self.num_envs, self.num_agents, highs, self.device))
             self.simulator.handle.step()
         else:
-            rng = np.random.default_rng((self._seed, self._episode))
-            cue = (np.tile(self._cue_raw, (self.num_envs, 1)) if self.cue_actions == 'traffic'
-                   else rng.integers(0, n_cue, (self.num_envs, self.num_cues), dtype=np.int32))
-            a = np.concatenate([cue, rng.integers(0, n_due, (self.num_envs, self.num_due_pairs), dtype=np.int32)], axis=1)
+            a = _rng.uniform_ints_numpy(self._seed, self._episode, self.first_env, self.num_envs, self.num_agents, highs) \
+                if self.num_agents else np.zeros((self.num_envs, 0), np.int32)
             self.simulator.step_arrays(a)
+        self._episode += 1
+        if self.simulator.handle.status_flags() & _native.FLAG_ZERO_DISTANCE:
+            raise ValueError('math domain error')            # log10(0) in path_loss.py:66
         return self._observe(self._view())
 
     def step(self, actions):
-        """actions: int [B, num_agents] (torch CUDA tensor, or NumPy).  Returns (obs, rewards[B,N], dones[B], info)."""
+        """actions: int [B, num_agents] (torch CUDA tensor, or NumPy).  Returns (obs, rewards[B,N], dones[B], info).
+        Asynchronous on the torch path: nothing here waits for the GPU, so error flags are NOT checked per step -
+        see status_flags()."""
         sim = self.simulator
         if self.use_torch:
             self._follow_torch_stream()
-            a = self._t['actions']
             src = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions), device=self.device)
             if tuple(src.shape) != (self.num_envs, self.num_agents):
                 raise ValueError(f'actions must be [{self.num_envs},{self.num_agents}], got {tuple(src.shape)}')
-            if self.cue_actions == 'traffic':
-                a[:, :self.num_cues] = self._cue_raw_tensor()
-                a[:, self.num_cues:] = src
-            elif src.data_ptr() != a.data_ptr():
-                a.copy_(src)
-            sim.handle.step()
+            if src.dtype == torch.int32 and src.is_contiguous() and src.device == self.device:
+                sim.handle.step(src.data_ptr())               # zero copy: the kernel reads the caller's tensor
+            else:
+                self._t['actions'].copy_(src)
+                sim.handle.step()
         else:
             src = np.asarray(actions, dtype=np.int32)
             if src.shape != (self.num_envs, self.num_agents):
                 raise ValueError(f'actions must be [{self.num_envs},{self.num_agents}], got {src.shape}')
-            if self.cue_actions == 'traffic':
-                src = np.concatenate([np.tile(self._cue_raw, (self.num_envs, 1)), src], axis=1)
             sim.step_arrays(src)
         self.num_steps += 1
         view = self._view()
@@ -210,18 +217,14 @@ class VecD2DEnv:
                 'rate_bps': view.rate_bps, 'capacity_mbps': view.capacity_mbps}
         return obs, rewards, dones, info
 
-    def _cue_raw_tensor(self):
-        if not hasattr(self, '_cue_raw_t'):
-            self._cue_raw_t = torch.as_tensor(self._cue_raw, device=self.device)
-        return self._cue_raw_t
-
     def _observe(self, view):
         if isinstance(self.obs_fn, ArrayObsFunction):
             return self.obs_fn.compute(view)
         return view.obs
 
     def action_buffer(self):
-        """The bound int32 [B, N] action tensor: writing actions straight into it avoids the copy in step()."""
+        """The bound int32 [B, num_agents] action tensor (step() with no copy also accepts any contiguous int32 CUDA
+        tensor of that shape)."""
         return self._t.get('actions')
 
     def status_flags(self) -> int:

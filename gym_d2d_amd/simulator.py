@@ -63,7 +63,7 @@ class NativeState(dict):
         super().__init__()
         self.arrays = arrays
         for name, _ in self.FIELDS:
-            self[name] = {ids: float(v) for ids, v in zip(keys, arrays[name])}
+            self[name] = dict(zip(keys, arrays[name].tolist()))        # Python floats, as the reference's dicts hold
         self.linear_obs: Optional[np.ndarray] = None
         self.obs_table: Optional[np.ndarray] = None
         self.native_reward: Optional[np.ndarray] = None
@@ -249,16 +249,29 @@ class Simulator:
 
     # ------------------------------------------------------------------ step
     def step(self, actions: Actions) -> NativeState:
-        """Single-env, object-level entry (simulator.py:77-87): actions -> state dict, computed on the GPU."""
+        """Single-env, object-level entry (simulator.py:77-87): actions -> state dict, computed on the GPU.  One packed
+        host -> device copy of (rb, pwr), the kernels, one packed device -> host copy of every result (d2d_step_host)."""
         if self.num_envs != 1:
             raise ValueError('Simulator.step(Actions) is the single-env entry; use step_arrays for batches')
         if len(actions) == 0:
             raise ZeroDivisionError('division by zero')      # what reward_fn.py:42 does with no actions
         self.set_links(actions.keys())
-        rb = np.array([[a.rb for a in actions.values()]], dtype=np.int32)
-        pwr = np.array([[int(a.tx_pwr_dBm) for a in actions.values()]], dtype=np.int32)
-        self.step_arrays(rb=rb, pwr=pwr)
-        return self.state_of_env(0)
+        acts = list(actions.values())
+        rb = np.array([[a.rb for a in acts]], dtype=np.int32)
+        pwr = np.array([[int(a.tx_pwr_dBm) for a in acts]], dtype=np.int32)
+        res = self.handle.step_host(rb, pwr)
+        if int(res['env_flags'][0]) & _native.FLAG_ZERO_DISTANCE:
+            raise ValueError('math domain error')            # log10(0) in path_loss.py:66
+        arrays = {'sinrs_db': res['sinr_db'][0].astype(np.float64), 'snrs_db': res['snr_db'][0].astype(np.float64),
+                  'rate_bps': res['rate_bps'][0].astype(np.float64), 'capacity_mbps': res['capacity'][0].astype(np.float64)}
+        if self._table_route and not all(np.isfinite(v).all() for v in arrays.values()):
+            raise ValueError('math domain error')            # the user's PathLoss could not evaluate a used pair
+        state = NativeState(self._link_keys, arrays)
+        state.obs_table = res['obs_table'][0].astype(np.float64)
+        if 'obs' in res:
+            state.linear_obs = res['obs'][0].astype(np.float64)
+        state.native_reward = res['reward'][0].astype(np.float64)
+        return state
 
     def step_arrays(self, actions: Optional[np.ndarray] = None, *, rb: Optional[np.ndarray] = None,
                     pwr: Optional[np.ndarray] = None, actions_ptr: int = 0) -> None:
@@ -269,9 +282,11 @@ class Simulator:
             h.step(actions_ptr)
         elif actions is not None:
             a = np.ascontiguousarray(actions, dtype=np.int32)
-            if a.shape != (self.num_envs, h.num_links):
-                raise ValueError(f'actions must be [{self.num_envs},{h.num_links}], got {a.shape}')
-            h.upload(_native.BUF_ACTIONS, a)
+            n_agents = h.num_links - h.num_fixed
+            if a.shape != (self.num_envs, n_agents):
+                raise ValueError(f'actions must be [{self.num_envs},{n_agents}], got {a.shape}')
+            if n_agents:
+                h.upload(_native.BUF_ACTIONS, a)
             h.step()
         else:
             r = np.ascontiguousarray(rb, dtype=np.int32); p = np.ascontiguousarray(pwr, dtype=np.int32)

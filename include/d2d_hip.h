@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 1
+#define D2D_ABI_VERSION 2
 #define D2D_MAX_LINKS 2048      /* links per env the step kernel's LDS staging is sized for */
+#define D2D_UNIQUE_ID_BYTES 128 /* size of an RCCL unique id (ncclUniqueId)                  */
 
 typedef struct d2d_handle d2d_handle;
 
@@ -60,7 +61,8 @@ typedef enum d2d_obs_mode {
 typedef enum d2d_buffer {
     D2D_BUF_POS_X = 0,      /* f32 [B,D]   device x positions (simulator.py:61-75)                  */
     D2D_BUF_POS_Y = 1,      /* f32 [B,D]                                                            */
-    D2D_BUF_ACTIONS = 2,    /* i32 [B,N]   raw discrete actions (d2d_env.py:93-96)                  */
+    D2D_BUF_ACTIONS = 2,    /* i32 [B,A]   raw discrete actions (d2d_env.py:93-96); A = N minus the
+                               links given fixed actions by d2d_set_fixed_actions                   */
     D2D_BUF_RB = 3,         /* i32 [B,N]   decoded resource block                                   */
     D2D_BUF_PWR = 4,        /* i32 [B,N]   decoded tx power, dBm                                    */
     D2D_BUF_SINR_DB = 5,    /* f32 [B,N]   state['sinrs_db']       (simulator.py:89-108)            */
@@ -143,6 +145,18 @@ int d2d_set_path_loss_table(d2d_handle* h, const float* pl_db, int32_t per_env);
 int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const int32_t* rx_dev,
                   const int32_t* link_type);
 
+/* TrafficModel plugin (traffic_model.py:6-32; the hook the reference left commented out at
+ * simulator.py:78): links whose (rb, tx_pwr_dBm) are NOT chosen by an agent.  link_idx[] indexes the
+ * link list of the last d2d_set_links; rb[] / pwr_dbm[] are the constants UplinkTrafficModel /
+ * DownlinkTrafficModel.get_traffic would produce (rb = k mod num_rbs, pwr = device max power).  They
+ * are stored in the per-link records the step kernel reads anyway, so d2d_step then takes actions for
+ * the remaining A = n_links - n_fixed links only: actions_dev is i32 [B, A], columns in link order
+ * with the fixed links skipped.  (rb, pwr) are used as given - no a // P decode - so any power is
+ * legal, as with the reference's Action(rb, pwr).  d2d_step_rb_pwr keeps the full [B, N] layout and
+ * ignores the entries of fixed links.  n_fixed = 0 (or a new d2d_set_links) clears the set.          */
+int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_idx, const int32_t* rb,
+                          const int32_t* pwr_dbm);
+
 /* RewardFunction / ObsFunction plugin selection (d2d_env.py:27-28).                                */
 int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param);
 int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode);
@@ -152,12 +166,18 @@ int d2d_set_bucketing(d2d_handle* h, int32_t enabled);
 
 /* Launch-geometry knobs (performance only, results do not change).                                 */
 typedef enum d2d_tuning {
-    D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* obs rows written per workgroup; 0 = auto (~512 KiB per WG)     */
+    D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* obs rows written per workgroup; 0 = auto                       */
     D2D_TUNE_OBS_NONTEMPORAL = 1,  /* 1 (default): nontemporal stores for the obs stream             */
     D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
     D2D_TUNE_OBS_BLOCK = 3,        /* threads per obs workgroup; 0 = auto                            */
     D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): T staged in LDS; 1: T read from global (A/B)      */
-    D2D_TUNE_STEP_THREADS = 5      /* threads per step workgroup (one env); 0 = auto                 */
+    D2D_TUNE_STEP_THREADS = 5,     /* threads per ENV in the step kernel; 0 = auto (one per link)    */
+    D2D_TUNE_STEP_ENVS_PER_WG = 6, /* envs sharing one step workgroup; 0 = auto                      */
+    D2D_TUNE_STEP_BLOCK = 7,       /* threads per step workgroup (>= envs * threads/env); 0 = auto   */
+    D2D_TUNE_STEP_VARIANT = 8,     /* same-RB interferer search: 0 bitmask walk, 1 RB-sorted buckets
+                                      (stable counting sort); -1 = auto.  Bit-identical results.     */
+    D2D_TUNE_STEP_FUSE_OBS = 9     /* LinearObs expansion inside the step launch: 1 on, 0 off,
+                                      -1 = auto (on for small N, where two launches are latency bound) */
 } d2d_tuning;
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
 
@@ -171,6 +191,12 @@ int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes,
 int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset);
 /* Simulator.reset (simulator.py:61-75) with host-supplied positions: x,y [env_count, D] f32.       */
 int d2d_set_positions(d2d_handle* h, const float* x, const float* y, int32_t env_begin, int32_t env_count);
+
+/* The step kernel reads per-LINK position rows (tx_x, tx_y, rx_x, rx_y) that the library derives from
+ * POS_X / POS_Y whenever it knows they changed (d2d_set_positions, d2d_upload, d2d_reset_positions,
+ * d2d_bind_buffer, d2d_set_links).  A caller that writes device positions straight into a BOUND
+ * buffer (its own kernel / a torch op) must say so before the next step.                             */
+int d2d_positions_changed(d2d_handle* h);
 
 /* Simulator.reset on the device (simulator.py:61-75; samplers position.py:18-45) for all B envs:
  * BS at the origin, CUEs / DUE transmitters uniform in the cell disc, DUE receivers uniform within
@@ -190,8 +216,46 @@ int d2d_step(d2d_handle* h, const int32_t* actions_dev);
 /* Same with (rb, tx_pwr_dBm) given explicitly - the ndarray action form (d2d_env.py:97-98).
  * NULL pointers read D2D_BUF_RB / D2D_BUF_PWR.                                                     */
 int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev);
+/* LinearObsFunction.get_state (obs_fn.py:43-53) on a table the CALLER holds - e.g. the compact tables a
+ * learner received from other GPUs: table_dev f32 [n_envs, n_links, 6] -> obs_dev f32
+ * [n_envs, n_links, 6*n_links], same kernel and bit-identical to the D2D_BUF_OBS the owning GPU
+ * produced.  Independent of the handle's own B / N; asynchronous on the handle's stream.            */
+int d2d_expand_table(d2d_handle* h, const float* table_dev, int32_t n_envs, int32_t n_links, float* obs_dev);
+
+/* D2DEnv.step for host callers (the single-env drop-in, d2d_env.py:62-71): (rb, pwr) [B,N] from HOST
+ * memory in, every result of the step back in ONE pinned host block - one H2D copy, the kernels, one
+ * D2H copy, one synchronisation.  *out_host points at library-owned pinned memory laid out as
+ * d2d_host_layout says (offsets in bytes), valid until the next call on this handle.  The D2D_BUF_*
+ * output buffers are NOT updated by this entry.                                                      */
+typedef struct d2d_host_layout {
+    size_t sinr_db, snr_db, rate_bps, capacity, reward;   /* f32 [B,N] each                          */
+    size_t rb, pwr;                                       /* i32 [B,N]                               */
+    size_t obs_table;                                     /* f32 [B,N,6]                             */
+    size_t env_flags;                                     /* i32 [B]                                 */
+    size_t obs;                                           /* f32 [B,N,6N] (obs mode LINEAR only)     */
+    size_t total_bytes;
+} d2d_host_layout;
+int d2d_step_host(d2d_handle* h, const int32_t* rb_host, const int32_t* pwr_host, const void** out_host,
+                  d2d_host_layout* layout);
+
 /* OR of D2D_FLAG_* over all envs of the last step (synchronises the stream).                       */
 int d2d_status_flags(d2d_handle* h, uint32_t* flags);
+
+/* ---- multi-GPU: the end-of-step concat --------------------------------------- */
+/* Environments are independent (simulator.py:95, reward_fn.py:42, obs_fn.py:46-51), so one process per
+ * GPU steps its own env block with no exchange; the only collective is an all-gather of what a single
+ * learner reads at the end of a step.  These entry points run it over RCCL (xGMI) without Python:
+ * rank 0 makes an id (d2d_comm_unique_id), ships the 128 bytes to the other ranks by any means, every
+ * rank calls d2d_comm_init, then d2d_allgather(send, recv, bytes, stream) enqueues ncclAllGather:
+ * recv_dev holds world * bytes_per_rank, rank-major = global env order.  hip_stream = NULL runs it on the
+ * handle's stream (in order with the step); a caller that wants the gather to overlap the obs expansion
+ * and the next step passes its own side stream and orders it with events, as StepGatherer does.
+ * librccl is dlopen()ed on first use (D2D_RCCL_LIBRARY overrides the path), so single-GPU users need no
+ * RCCL at all.                                                                                          */
+int d2d_comm_unique_id(void* id_out /* D2D_UNIQUE_ID_BYTES */);
+int d2d_comm_init(d2d_handle* h, int32_t world_size, int32_t rank, const void* unique_id);
+int d2d_comm_destroy(d2d_handle* h);
+int d2d_allgather(d2d_handle* h, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* hip_stream);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* When enabled, every kernel launched by d2d_step is bracketed by hipEvents on the handle's stream. */

@@ -409,11 +409,12 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def reset_uniforms(seed, episode, num_envs, num_devices, tries, first_env=0):
-    """The uniforms the device-side reset consumes: u[b, d, t, 0] -> theta, u[b, d, t, 1] -> radius, each
-    (word >> 8) * 2^-24 with counter (first_env + b, d, t, episode) and key = 64-bit seed."""
+    """The uniforms the device-side reset consumes, counter (first_env + b, d, t, episode), key = 64-bit seed:
+    u[b, d, t, 0] -> theta = (word0 >> 8) * 2^-24 in [0, 1); u[b, d, t, 1] -> radius = ((word1 >> 8) + 0.5) * 2^-24
+    in the OPEN interval (0, 1), so no device is ever placed at distance 0 from its anchor."""
     b = (np.arange(num_envs, dtype=np.uint64) + np.uint64(first_env))[:, None, None]
     d = np.arange(num_devices, dtype=np.uint64)[None, :, None]
     t = np.arange(tries, dtype=np.uint64)[None, None, :]
     w = philox4x32_10(b, d, t, np.uint64(episode & 0xFFFFFFFF), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     scale = 2.0 ** -24
-    return np.stack([(w[0] >> np.uint32(8)) * scale, (w[1] >> np.uint32(8)) * scale], axis=-1)
+    return np.stack([(w[0] >> np.uint32(8)) * scale, ((w[1] >> np.uint32(8)) + 0.5) * scale], axis=-1)

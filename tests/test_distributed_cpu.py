@@ -85,3 +85,77 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     assert np.array_equal(np.load(tmp_path / 'table.npy'), table)
     # the learner-side expansion of the gathered compact table == the expanded obs every rank holds locally
     assert np.array_equal(np.load(tmp_path / 'obs.npy'), obs)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gym_d2d_amd.distributed import StepGatherer, shard_range
+    begin, end = shard_range(7, world, rank)                     # 4 + 3 envs
+    try:
+        StepGatherer(end - begin, 5, torch.device('cpu'))
+        msg = 'no error'
+    except ValueError as exc:
+        msg = str(exc)
+    (Path(out_dir) / f'rank{rank}.txt').write_text(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_are_rejected_up_front(tmp_path):
+    """all_gather_into_tensor needs equal shards: StepGatherer must say so instead of hanging in the collective."""
+    mp.spawn(_uneven_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        assert 'equal shards' in (tmp_path / f'rank{rank}.txt').read_text()
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop('RANK', None); env.pop('WORLD_SIZE', None); env.pop('LOCAL_RANK', None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py')] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return r, ([json.loads(lines[0])] if len(lines) == 1 and r.returncode == 0 else lines)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent spawns both ranks, rank 0 prints exactly one
+    JSON line, the collectives saw 2 ranks and the gathered rewards are the ones the ranks produced (stub handle on
+    CPU / gloo - the per-GPU step itself is covered by the -m gpu tests)."""
+    r, out = _run_bench(['--gpus', '2', '--stub-cpu', '--steps', '3', '--warmup', '1', '--envs', '4', '--workload', 'default'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1 and isinstance(out[0], dict), r.stdout
+    line = out[0]
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['allreduce_rank_count'] == 2.0
+    assert line['allgather_envs'] == 8 and line['checksums_agree'] is True
+    # stub rewards: env block of rank r holds (r * 4 + steps_done) in every env -> sum over 8 envs
+    steps_done = 4
+    assert line['allreduce_reward_checksum'] == 4 * (0 + steps_done) + 4 * (4 + steps_done)
+    assert line['value'] > 0 and line['config']['envs_per_gpu'] == 4 and 'stub' in line
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    r, out = _run_bench(['--gpus', '2', '--stub-cpu', '--steps', '2', '--warmup', '1', '--envs', '4', '--workload', 'default'],
+                        env_extra={'D2D_BENCH_TEST_FAIL_RANK': '1'})
+    assert r.returncode != 0
+    assert 'rank 1 exited' in r.stderr
+
+
+def test_bench_runs_as_a_rank_under_an_external_launcher():
+    """The driver's form: RANK / WORLD_SIZE already set by torch.distributed.run -> bench.py is a rank, not a launcher."""
+    import subprocess
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--stub-cpu', '--steps', '2',
+                                       '--warmup', '1', '--envs', '4', '--workload', 'default'], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    assert json.loads(outs[0][0].strip())['rccl_ranks'] == 2 and outs[1][0].strip() == ''

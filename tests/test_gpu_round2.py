@@ -1,0 +1,362 @@
+"""GPU tests of the round-2 additions, through the C ABI: interferer-search variants and launch geometries are
+bit-identical, BASELINE config 2 exactly as stated, traffic-model links held in the kernel's records, the gather-side
+entry points (d2d_expand_table, d2d_comm_* / d2d_allgather) and the packed host step (d2d_step_host)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from golden_util import load_case, rel_err
+from oracle import d2d_oracle as orc
+from sim_util import default_links, random_layout
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+OUTS = ('BUF_SINR_DB', 'BUF_SNR_DB', 'BUF_RATE_BPS', 'BUF_CAPACITY', 'BUF_REWARD', 'BUF_OBS_TABLE', 'BUF_RB', 'BUF_PWR',
+        'BUF_ENV_FLAGS')
+
+
+@pytest.fixture(scope='module')
+def native():
+    from gym_d2d_amd import _native
+    _native.load_library()
+    return _native
+
+
+def _batch(native, num_envs, rbs, cues, dues, seed, **cfg):
+    from gym_d2d_amd.simulator import Simulator
+    rng = np.random.default_rng(seed)
+    sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=num_envs, **cfg))
+    pos = random_layout(rng, num_envs, cues, dues)
+    sim.set_positions(pos)
+    sim.set_links(sim.default_link_keys())
+    p = sim.config.num_pwr_actions
+    raw = np.concatenate([rng.integers(0, rbs * p['cue'], (num_envs, cues)),
+                          rng.integers(0, rbs * p['due'], (num_envs, dues))], axis=1).astype(np.int32)
+    return sim, pos, raw
+
+
+def _snapshot(sim, native, with_obs):
+    out = {name: sim.fetch(getattr(native, name)).copy() for name in OUTS}
+    if with_obs:
+        out['BUF_OBS'] = sim.fetch(native.BUF_OBS).copy()
+    return out
+
+
+@pytest.mark.parametrize('shape', [(33, 25, 25, 25), (24, 256, 256, 256), (16, 4, 40, 60), (8, 7, 0, 130), (5, 300, 100, 91),
+                                   (9, 1, 64, 64)])
+@pytest.mark.parametrize('reward', [1, 2, 3])
+def test_interferer_search_variants_are_bit_identical(native, shape, reward):
+    """Bitmask walk, RB-sorted buckets (stable counting sort) and the masked all-pairs sweep visit interferers in the
+    same ascending link order through the same fmaf: every output must agree bit for bit (and match the oracle)."""
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(native, b, rbs, cues, dues, seed=sum(shape) + reward)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+    h.set_reward(reward, {1: 0.0, 2: -70.0, 3: 0.0}[reward])
+    snaps = {}
+    for name, bucket, variant in (('mask_walk', True, native.STEP_MASK_WALK), ('rb_sorted', True, native.STEP_RB_SORTED),
+                                  ('all_pairs', False, native.STEP_MASK_WALK)):
+        h.set_bucketing(bucket)
+        h.set_tuning(native.TUNE_STEP_VARIANT, variant)
+        sim.step_arrays(raw)
+        snaps[name] = _snapshot(sim, native, False)
+    for name in ('rb_sorted', 'all_pairs'):
+        for buf, ref in snaps['mask_walk'].items():
+            assert np.array_equal(snaps[name][buf], ref), (name, buf)
+    ids, cfgs, is_bs = orc.device_configs(cues, dues)
+    tx, rx, ty = default_links(cues, dues)
+    ref = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(cfgs, is_bs), orc.PathLossSpec(),
+                        with_obs=False, chunk=8)
+    assert rel_err(snaps['rb_sorted']['BUF_SINR_DB'], ref['sinr_db']) <= TOL
+    assert rel_err(snaps['rb_sorted']['BUF_CAPACITY'], ref['capacity_mbps']) <= TOL
+    if reward == 1:
+        assert rel_err(snaps['rb_sorted']['BUF_REWARD'][:, 0], ref['reward']) <= TOL
+    elif reward == 2:
+        assert rel_err(snaps['rb_sorted']['BUF_REWARD'], orc.reward_shannon(ref['sinr_db'])) <= TOL
+    else:
+        assert rel_err(snaps['rb_sorted']['BUF_REWARD'], orc.reward_cue_sinr_shannon(ref['sinr_db'], ref['rb'], ty)) <= TOL
+    sim.handle.close()
+
+
+@pytest.mark.parametrize('shape', [(13, 25, 25, 25), (7, 5, 9, 10), (10, 3, 30, 37), (6, 16, 50, 50)])
+def test_envs_per_workgroup_and_fused_obs_are_bit_identical(native, shape):
+    """Small envs share a workgroup and the LinearObs expansion may run inside the step launch: neither changes a bit
+    of any output, for batch sizes that do not divide by the envs per workgroup and for odd N (8-byte obs stores)."""
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(native, b, rbs, cues, dues, seed=sum(shape))
+    h = sim.handle
+    h.set_obs_mode(native.OBS_LINEAR)
+    ref = None
+    for variant in (native.STEP_MASK_WALK, native.STEP_RB_SORTED):
+        for epw, fuse, block in ((1, 0, 0), (1, 1, 0), (2, 1, 0), (4, 0, 0), (4, 1, 512), (3, 1, 1024), (0, -1, 0)):
+            if epw * ((cues + dues + 63) // 64) * 64 > 1024:
+                continue
+            h.set_tuning(native.TUNE_STEP_VARIANT, variant)
+            h.set_tuning(native.TUNE_STEP_ENVS_PER_WG, epw)
+            h.set_tuning(native.TUNE_STEP_FUSE_OBS, fuse)
+            h.set_tuning(native.TUNE_STEP_BLOCK, block)
+            h.upload(native.BUF_OBS, np.full((b, cues + dues, 6 * (cues + dues)), np.nan, np.float32))
+            sim.step_arrays(raw)
+            snap = _snapshot(sim, native, True)
+            if ref is None:
+                ref = snap
+                want = orc.full_step(pos.astype(np.float64), *default_links(cues, dues), raw,
+                                     orc.device_columns(*orc.device_configs(cues, dues)[1:]), orc.PathLossSpec())
+                assert rel_err(snap['BUF_OBS'], want['obs']) <= TOL
+                assert (snap['BUF_OBS'] == orc.expand_obs(snap['BUF_OBS_TABLE'])).all()
+            for buf, r in ref.items():
+                assert np.array_equal(snap[buf], r, equal_nan=True), (variant, epw, fuse, block, buf)
+    sim.handle.close()
+
+
+def test_baseline_config_2_exactly_as_stated(native):
+    """BASELINE.json configs[1]: 1024 envs x (25 CUE + 25 DUE pairs, 25 RB), LogDistance, UplinkTrafficModel-driven CUEs
+    (traffic_model.py:15-22): agents supply DUE actions only.  Every output of every env against the oracle."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    b, c, p, r = 1024, 25, 25, 25
+    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p}, num_envs=b, cue_actions='traffic')
+    obs = env.reset(seed=2024)
+    assert env.num_agents == p and tuple(obs.shape) == (b, 50, 300) and tuple(env.action_buffer().shape) == (b, p)
+    pos = env.simulator.positions().astype(np.float64)
+    ids, cfgs, is_bs = orc.device_configs(c, p)
+    cols = orc.device_columns(cfgs, is_bs)
+    tx, rx, ty = default_links(c, p)
+    rng = np.random.default_rng(5)
+    to_np = lambda t: t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    for k in range(3):
+        due = rng.integers(0, r * 21, (b, p)).astype(np.int32)
+        act = torch.as_tensor(due, device=env.device) if env.use_torch else due
+        obs, rew, dones, info = env.step(act)
+        rb = np.concatenate([np.tile(np.arange(c) % r, (b, 1)), due // 21], axis=1)
+        pwr = np.concatenate([np.full((b, c), 23), due % 21], axis=1)
+        assert (to_np(info['rb']) == rb).all() and (to_np(info['tx_pwr_dbm']) == pwr).all()
+        st = orc.step(pos, tx, rx, rb, pwr, cols, orc.PathLossSpec(), chunk=64)
+        for f in ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps'):
+            assert rel_err(to_np(info[f]), st[f]) <= TOL, (k, f)
+        reward = orc.reward_system_capacity(st['capacity_mbps'], rb, ty)
+        assert rel_err(to_np(rew), np.repeat(reward[:, None], 50, 1)) <= TOL
+        table = orc.obs_table(pos, tx, rx, st['sinr_db'], st['snr_db'])
+        got_obs = to_np(obs)
+        assert rel_err(got_obs, orc.expand_obs(table)) <= TOL
+        assert (got_obs == orc.expand_obs(to_np(env._t['table']) if env.use_torch else env.simulator.fetch(native.BUF_OBS_TABLE))).all()
+    assert env.status_flags() == 0
+    env.close()
+
+
+def test_fixed_actions_take_any_power_and_skip_the_decode(native):
+    """a CUE whose device_config max_tx_power_dBm is above the 24-level CUE alphabet must keep its power
+    when the traffic model drives it - (rb, pwr) live in the link records, there is no a // P round trip."""
+    from gym_d2d_amd.envs import VecD2DEnv
+    import json, tempfile, pathlib
+    over = {'cue01': {'position': [120.0, -40.0],
+                      'config': {'num_subcarriers': 12, 'subcarrier_spacing_kHz': 15, 'max_tx_power_dBm': 30}}}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = pathlib.Path(tmp) / 'cfg.json'
+        path.write_text(json.dumps(over))
+        env = VecD2DEnv({'num_rbs': 3, 'num_cues': 4, 'num_due_pairs': 5, 'device_config_file': path}, num_envs=8,
+                        cue_actions='traffic', use_torch=False)
+        env.reset(seed=3)
+        due = np.random.default_rng(0).integers(0, 3 * 21, (8, 5)).astype(np.int32)
+        obs, rew, dones, info = env.step(due)
+        assert (info['tx_pwr_dbm'][:, :4] == [23, 30, 23, 23]).all() and (info['rb'][:, :4] == [0, 1, 2, 0]).all()
+        pos = env.simulator.positions().astype(np.float64)
+        ids, cfgs, is_bs = orc.device_configs(4, 5, overrides={k: v['config'] for k, v in over.items()})
+        tx, rx, ty = default_links(4, 5)
+        st = orc.step(pos, tx, rx, info['rb'], info['tx_pwr_dbm'], orc.device_columns(cfgs, is_bs), orc.PathLossSpec())
+        assert rel_err(info['sinr_db'], st['sinr_db']) <= TOL and rel_err(info['snr_db'], st['snr_db']) <= TOL
+        env.close()
+
+
+def test_fixed_actions_through_the_c_abi(native):
+    """d2d_set_fixed_actions directly: argument checking, compact [B, A] action layout with fixed links in the MIDDLE
+    of the link list, the explicit rb/pwr form keeping the full layout, and clearing."""
+    sim, pos, raw = _batch(native, 6, 5, 4, 6, seed=11)
+    h = sim.handle
+    with pytest.raises(native.NativeError, match='out of range'):
+        h.set_fixed_actions([10], [0], [0])
+    with pytest.raises(native.NativeError, match='twice'):
+        h.set_fixed_actions([1, 1], [0, 0], [0, 0])
+    fixed_idx, fixed_rb, fixed_pw = [1, 6, 9], [4, 0, 2], [17, 3, 40]
+    h.set_fixed_actions(fixed_idx, fixed_rb, fixed_pw)
+    keep = [i for i in range(10) if i not in fixed_idx]
+    assert h.buffer_shape(native.BUF_ACTIONS) == (6, 7)
+    sim.step_arrays(raw[:, keep])
+    p = sim.config.num_pwr_actions
+    levels = np.array([p['cue']] * 4 + [p['due']] * 6)
+    rb, pwr = raw // levels, raw % levels
+    rb[:, fixed_idx] = fixed_rb; pwr[:, fixed_idx] = fixed_pw
+    assert (sim.fetch(native.BUF_RB) == rb).all() and (sim.fetch(native.BUF_PWR) == pwr).all()
+    ids, cfgs, is_bs = orc.device_configs(4, 6)
+    tx, rx, ty = default_links(4, 6)
+    st = orc.step(pos.astype(np.float64), tx, rx, rb, pwr, orc.device_columns(cfgs, is_bs), orc.PathLossSpec())
+    assert rel_err(sim.fetch(native.BUF_SINR_DB), st['sinr_db']) <= TOL
+    first = sim.fetch(native.BUF_SINR_DB).copy()
+    # explicit form: full [B, N] arrays, entries of fixed links are ignored
+    junk_rb, junk_pw = rb.copy(), pwr.copy()
+    junk_rb[:, fixed_idx] = 3; junk_pw[:, fixed_idx] = 1
+    sim.step_arrays(rb=junk_rb, pwr=junk_pw)
+    assert np.array_equal(sim.fetch(native.BUF_SINR_DB), first)
+    h.set_fixed_actions([], [], [])
+    sim.step_arrays(raw)
+    assert (sim.fetch(native.BUF_RB) == raw // levels).all()
+    sim.handle.close()
+
+
+def test_expand_table_of_a_gathered_table_is_bit_identical_to_the_local_obs(native):
+    """d2d_expand_table (the learner-side expansion of tables received from other GPUs) runs the same kernel: the
+    expansion of a one-rank 'gathered' table equals the D2D_BUF_OBS the owning handle produced, bit for bit - at a
+    size the step fuses (N = 24) and at one it does not (N = 192), and on a handle with a different B / N."""
+    import torch
+    from gym_d2d_amd.distributed import expand_table, expand_table_torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    other = VecD2DEnv({'num_rbs': 2, 'num_cues': 1, 'num_due_pairs': 1}, num_envs=2)
+    for cues, dues, b in ((10, 14, 40), (96, 96, 16), (5, 6, 3)):
+        env = VecD2DEnv({'num_rbs': 9, 'num_cues': cues, 'num_due_pairs': dues}, num_envs=b)
+        obs = env.reset(seed=1)
+        gathered = env._t['table'].clone()                  # what an all-gather with one rank delivers
+        for h in (env.simulator.handle, other.simulator.handle):
+            out = expand_table(gathered, h)
+            torch.cuda.synchronize()
+            assert torch.equal(out, obs)
+        assert torch.equal(expand_table_torch(gathered.cpu()), obs.cpu())
+        with pytest.raises(ValueError, match='native handle'):
+            expand_table(gathered)
+        env.close()
+    other.close()
+
+
+def test_native_rccl_allgather_single_rank(native):
+    """d2d_comm_unique_id / d2d_comm_init / d2d_allgather: RCCL reached through the C ABI (dlopen), one rank - the
+    gathered buffer is the sent one, on the handle's stream and on a caller's side stream."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    env = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 4}, num_envs=32)
+    env.reset(seed=1)
+    h = env.simulator.handle
+    with pytest.raises(native.NativeError, match='d2d_comm_init'):
+        h.allgather(env._t['table'].data_ptr(), env._t['table'].data_ptr(), 16)
+    uid = h.comm_unique_id()
+    assert len(uid) == native.UNIQUE_ID_BYTES and any(uid)
+    h.comm_init(1, 0, uid)
+    src = env._t['table'].clone()
+    dst = torch.zeros_like(src)
+    h.allgather(src.data_ptr(), dst.data_ptr(), src.numel() * 4)
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    side = torch.cuda.Stream(device=env.device)
+    dst.zero_()
+    side.wait_stream(torch.cuda.current_stream(env.device))
+    h.allgather(src.data_ptr(), dst.data_ptr(), src.numel() * 4, side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(src, dst)
+    h.comm_destroy()
+    env.close()
+
+
+def test_step_gatherer_native_backend_single_rank(native):
+    """StepGatherer(backend='native') = the torch-free gather path; with one rank it must reproduce the local results."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from gym_d2d_amd.distributed import StepGatherer
+    from gym_d2d_amd.envs import VecD2DEnv
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        env = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 4}, num_envs=16)
+        env.reset(seed=1)
+        g = StepGatherer(16, 7, env.device, backend='native', handle=env.simulator.handle)
+        g.gather_positions(env._t['table'])
+        act = torch.randint(0, 4 * 21, (16, 7), device=env.device, dtype=torch.int32)
+        env.step(act)
+        g.launch(env._t['reward'], env._t['table'])
+        reward, signal = g.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(reward, env._t['reward'][:, 0]) and torch.equal(g.table(), env._t['table'])
+        env.simulator.handle.comm_destroy()
+        env.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_host_returns_everything_in_one_block(native):
+    """d2d_step_host (the single-env drop-in's transport) against d2d_step_rb_pwr + per-buffer downloads, for a
+    fused-obs size and a two-kernel size, batch of 3."""
+    for cues, dues in ((6, 7), (80, 90)):
+        sim, pos, raw = _batch(native, 3, 8, cues, dues, seed=cues)
+        h = sim.handle
+        h.set_obs_mode(native.OBS_LINEAR)
+        p = sim.config.num_pwr_actions
+        levels = np.array([p['cue']] * cues + [p['due']] * dues)
+        rb, pwr = (raw // levels).astype(np.int32), (raw % levels).astype(np.int32)
+        sim.step_arrays(rb=rb, pwr=pwr)
+        want = _snapshot(sim, native, True)
+        res = h.step_host(rb, pwr)
+        for key, buf in (('sinr_db', 'BUF_SINR_DB'), ('snr_db', 'BUF_SNR_DB'), ('rate_bps', 'BUF_RATE_BPS'),
+                         ('capacity', 'BUF_CAPACITY'), ('reward', 'BUF_REWARD'), ('obs_table', 'BUF_OBS_TABLE'),
+                         ('env_flags', 'BUF_ENV_FLAGS'), ('obs', 'BUF_OBS')):
+            assert np.array_equal(res[key], want[buf]), (cues, key)
+        assert (res['rb'] == rb).all() and (res['pwr'] == pwr).all()
+        sim.handle.close()
+
+
+def test_single_env_step_latency_budget(native):
+    """the drop-in D2DEnv.step is one packed copy each way - a loose wall-clock ceiling so that a
+    regression back to per-buffer synchronous copies is caught (measured figures live in DESIGN.md / bench JSON)."""
+    import time
+    from gym_d2d_amd.envs import D2DEnv
+    env = D2DEnv({})
+    obs = env.reset()
+    acts = {k: env.action_space['due' if k.startswith('due') else 'cue'].sample() for k in obs}
+    for _ in range(20):
+        env.step(acts)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        env.step(acts)
+    ms = (time.perf_counter() - t0) / 200 * 1e3
+    env.close()
+    assert ms < 0.6, ms
+
+
+def test_device_reset_never_places_two_interacting_devices_together(native):
+    """the radius uniform is on the open interval, so no CUE lands on the BS and no DUE receiver
+    on its transmitter; VecD2DEnv.reset() checks the zero-distance flag once per reset."""
+    from gym_d2d_amd.envs import VecD2DEnv
+    env = VecD2DEnv({'num_rbs': 8, 'num_cues': 64, 'num_due_pairs': 64}, num_envs=2048, use_torch=False)
+    for ep in range(3):
+        env.reset(seed=ep)
+        pos = env.simulator.positions().astype(np.float64)
+        r_cue = np.hypot(pos[:, 1:65, 0], pos[:, 1:65, 1])
+        tx, rx = pos[:, 65::2], pos[:, 66::2]
+        d_pair = np.hypot(tx[..., 0] - rx[..., 0], tx[..., 1] - rx[..., 1])
+        assert r_cue.min() > 0.0 and d_pair.min() > 0.0
+        assert env.status_flags() & (native.FLAG_ZERO_DISTANCE | native.FLAG_NON_FINITE) == 0
+    # and the check itself: positions forced onto the base station are reported at reset-time granularity
+    xy = env.simulator.positions()
+    xy[5, 3] = 0.0
+    env.simulator.set_positions(xy)
+    env.step(np.zeros((2048, 128), np.int32))
+    assert env.status_flags() & native.FLAG_ZERO_DISTANCE
+    env.close()
+
+
+def test_positions_written_into_a_bound_buffer_need_positions_changed(native):
+    """The step kernel reads per-link position rows derived from POS_X / POS_Y; a caller that edits a BOUND position
+    tensor in place says so with d2d_positions_changed."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    env = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 4}, num_envs=8)
+    env.reset(seed=1)
+    act = torch.randint(0, 4 * 21, (8, 7), device=env.device, dtype=torch.int32)
+    _, _, _, info = env.step(act)
+    before = info['snr_db'].clone()
+    env._t['pos_x'][:, 1:] *= 0.5; env._t['pos_y'][:, 1:] *= 0.5            # every UE at half its distance
+    env.simulator.handle.positions_changed()
+    _, _, _, info = env.step(act)
+    torch.cuda.synchronize()
+    # inverse-square law: uplink SNRs rise by exactly 20 log10(2) dB
+    assert torch.allclose(info['snr_db'][:, :3] - before[:, :3], torch.full((8, 3), 6.0206, device=env.device), atol=1e-3)
+    env.close()

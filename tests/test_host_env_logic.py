@@ -19,6 +19,7 @@ class RecordingHandle:
         self.num_devices = 1 + kw['num_cues'] + 2 * kw['num_due_pairs']
         self.max_links = kw.get('max_links') or (kw['num_cues'] + kw['num_due_pairs'])
         self.num_links = 0
+        self.num_fixed = 0
         self.calls = []
         self.uploads = {}
         RecordingHandle.instances.append(self)
@@ -48,6 +49,21 @@ class RecordingHandle:
 
     def step(self, ptr=0): self._rec('step', ptr)
     def step_rb_pwr(self, a=0, b=0): self._rec('step_rb_pwr')
+    def positions_changed(self): self._rec('positions_changed')
+
+    def set_fixed_actions(self, idx, rb, pwr):
+        self.num_fixed = len(idx)
+        self._rec('fixed_actions', list(idx), list(rb), list(pwr))
+
+    def step_host(self, rb, pwr):
+        """d2d_step_host: (rb, pwr) in, every result in one block out - zeros here, with rb/pwr echoed."""
+        self.uploads[_native.BUF_RB] = np.array(rb); self.uploads[_native.BUF_PWR] = np.array(pwr)
+        self._rec('step_host')
+        b, n = self.num_envs, self.num_links
+        res = {k: np.zeros((b, n), np.float32) for k in ('sinr_db', 'snr_db', 'rate_bps', 'capacity', 'reward')}
+        res.update(rb=np.array(rb, np.int32), pwr=np.array(pwr, np.int32), obs_table=np.zeros((b, n, 6), np.float32),
+                   env_flags=np.zeros(b, np.int32), obs=np.zeros((b, n, 6 * n), np.float32))
+        return res
 
     def download(self, which, env_begin=0, env_count=None):
         b, n, d = (env_count or self.num_envs), self.num_links, self.num_devices
@@ -226,9 +242,11 @@ def test_vec_env_host_side(stub):
     assert h.last('reset')[:2] == (5, 1)                   # next episode, same seed
     due = np.arange(12, dtype=np.int32).reshape(6, 2)
     obs, rew, dones, info = env.step(due)
-    sent = h.uploads[_native.BUF_ACTIONS]
-    # CUE columns from UplinkTrafficModel: rb = i mod R, power 23 -> raw = rb * 24 + 23 (traffic_model.py:15-22)
-    assert sent[:, :3].tolist() == [[0 * 24 + 23, 1 * 24 + 23, 2 * 24 + 23]] * 6 and (sent[:, 3:] == due).all()
+    # CUE links from UplinkTrafficModel: rb = i mod R at the CUE's max power (traffic_model.py:15-22), handed over ONCE
+    # as fixed (rb, pwr) of links 0..2 - the per-step action array carries the DUE columns only
+    assert h.last('fixed_actions') == ([0, 1, 2], [0, 1, 2], [23, 23, 23])
+    assert sum(1 for n, _ in h.calls if n == 'fixed_actions') == 1
+    assert h.uploads[_native.BUF_ACTIONS].shape == (6, 2) and (h.uploads[_native.BUF_ACTIONS] == due).all()
     assert obs.shape == (6, 5, 30) and rew.shape == (6, 5) and dones.shape == (6,) and not dones.any()
     with pytest.raises(ValueError, match=r'\[6,2\]'):
         env.step(np.zeros((6, 5), dtype=np.int32))
@@ -239,7 +257,15 @@ def test_vec_env_host_side(stub):
     hd = stub.instances[-1]
     assert hd.last('links') == ([0, 0, 0, 4, 6], [1, 2, 3, 5, 7], [2, 2, 2, 3, 3])
     down.reset(seed=1)
-    assert hd.uploads[_native.BUF_ACTIONS][:, :3].tolist() == [[0 * 47 + 23, 1 * 47 + 23, 2 * 47 + 23]] * 2
+    assert hd.last('fixed_actions') == ([0, 1, 2], [0, 1, 2], [23, 23, 23]) and hd.uploads[_native.BUF_ACTIONS].shape == (2, 2)
+    # reset()'s random actions are keyed by global env index: a shard reproduces its slice of the unsharded batch
+    whole = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 2}, num_envs=8, use_torch=False)
+    whole.reset(seed=7)
+    part = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 2}, num_envs=3, use_torch=False, first_env=5)
+    part.reset(seed=7)
+    a_whole, a_part = stub.instances[-2].uploads[_native.BUF_ACTIONS], stub.instances[-1].uploads[_native.BUF_ACTIONS]
+    assert a_whole.shape == (8, 5) and (a_whole[5:8] == a_part).all()
+    assert (a_whole[:, :3] < 4 * 24).all() and (a_whole[:, 3:] < 4 * 21).all() and len(np.unique(a_whole)) > 10
     with pytest.raises(ValueError):
         VecD2DEnv({}, num_envs=2, cue_actions='nope', use_torch=False)
     from gym_d2d_amd.envs.obs_fn import ObsFunction

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""A/B sweeps of the step kernel, interleaved rounds in ONE process (HIP events around every launch):
+
+    python tools/ab_step.py stress     # 4096 x 512, compact-obs mode: mask walk vs RB-sorted vs all-pairs, per reward fn
+    python tools/ab_step.py default    # 1024 x 50, LinearObs: envs per workgroup x fused obs x block size
+    python tools/ab_step.py wall       # 1024 x 50: wall-clock per step (no per-launch events), fused vs two launches
+
+Prints one JSON line per variant; `--out file` also appends them to a file (profiles/r2_ab_*.jsonl are these).
+"""
+import argparse
+import json
+import statistics
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+from gym_d2d_amd import _native
+from gym_d2d_amd.envs import VecD2DEnv
+from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
+
+
+def emit(rec, out):
+    line = json.dumps(rec)
+    print(line, flush=True)
+    if out:
+        with open(out, 'a') as f:
+            f.write(line + '\n')
+
+
+def timed(h, act, launches, kernel=0):
+    h.profile_reset(); h.profile_enable(True)
+    for _ in range(launches):
+        h.step(act.data_ptr())
+    ms, k = h.profile_read(kernel)
+    h.profile_enable(False)
+    return ms / max(k, 1) * 1e3
+
+
+def stress(args):
+    b, c, p, r = 4096, 256, 256, 256
+    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
+    env.reset(seed=1)
+    h = env.simulator.handle
+    act = env.action_buffer()
+    variants = [(rw, name) for rw in (1, 0, 2, 3) for name in ('mask_walk', 'rb_sorted', 'all_pairs')]
+    times = {v: [] for v in variants}
+    for rnd in range(args.rounds):
+        for v in variants:
+            if v[1] == 'all_pairs' and rnd > 1:
+                continue
+            h.set_reward(v[0], {0: 0.0, 1: 0.0, 2: -70.0, 3: 0.0}[v[0]])
+            h.set_bucketing(v[1] != 'all_pairs')
+            h.set_tuning(_native.TUNE_STEP_VARIANT, _native.STEP_RB_SORTED if v[1] == 'rb_sorted' else _native.STEP_MASK_WALK)
+            times[v].append(timed(h, act, 10))
+    bytes_per = b * (c + p) * 64.0
+    for v in variants:
+        med = statistics.median(times[v])
+        emit({'sweep': 'stress_table_mode', 'reward_fn': v[0], 'variant': v[1], 'median_us': round(med, 2),
+              'min_us': round(min(times[v]), 2), 'algorithmic_GBps': round(bytes_per / med / 1e3), 'rounds': len(times[v])},
+             args.out)
+    env.close()
+
+
+def default(args):
+    b, c, p, r = 1024, 25, 25, 25
+    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': LinearObsFunction}, num_envs=b,
+                    cue_actions='traffic')
+    env.reset(seed=1)
+    h = env.simulator.handle
+    act = env.action_buffer()
+    variants = [(epw, fuse, blk, var) for var in (0, 1) for fuse in (1, 0) for epw in (1, 2, 4, 8)
+                for blk in ((0, 256, 512, 1024) if fuse else (0,)) if blk == 0 or blk >= epw * 64]
+    times = {v: [] for v in variants}
+    for rnd in range(args.rounds):
+        for v in variants:
+            h.set_tuning(_native.TUNE_STEP_ENVS_PER_WG, v[0])
+            h.set_tuning(_native.TUNE_STEP_FUSE_OBS, v[1])
+            h.set_tuning(_native.TUNE_STEP_BLOCK, v[2])
+            h.set_tuning(_native.TUNE_STEP_VARIANT, v[3])
+            t_step = timed(h, act, 20, 0)
+            t_obs = 0.0 if v[1] else timed(h, act, 20, 1)
+            times[v].append((t_step, t_obs))
+    for v in variants:
+        s_med = statistics.median(t[0] for t in times[v]); o_med = statistics.median(t[1] for t in times[v])
+        emit({'sweep': 'default_linear_obs', 'envs_per_wg': v[0], 'fuse_obs': v[1], 'block': v[2], 'variant': v[3],
+              'step_kernel_us': round(s_med, 2), 'obs_kernel_us': round(o_med, 2), 'sum_us': round(s_med + o_med, 2)}, args.out)
+    env.close()
+
+
+def wall(args):
+    b, c, p, r = 1024, 25, 25, 25
+    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': LinearObsFunction}, num_envs=b,
+                    cue_actions='traffic')
+    env.reset(seed=1)
+    h = env.simulator.handle
+    acts = torch.randint(0, r * 21, (64, b, p), device=env.device, dtype=torch.int32)
+    variants = [(epw, fuse, blk) for fuse in (1, 0) for epw in (0, 1, 2, 4) for blk in ((0, 512) if fuse else (0,))]
+    times = {v: [] for v in variants}
+    for rnd in range(args.rounds):
+        for v in variants:
+            h.set_tuning(_native.TUNE_STEP_ENVS_PER_WG, v[0])
+            h.set_tuning(_native.TUNE_STEP_FUSE_OBS, v[1])
+            h.set_tuning(_native.TUNE_STEP_BLOCK, v[2])
+            for k in range(20):
+                h.step(acts[k % 64].data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(500):
+                h.step(acts[k % 64].data_ptr())
+            torch.cuda.synchronize()
+            times[v].append((time.perf_counter() - t0) / 500 * 1e6)
+    for v in variants:
+        med = statistics.median(times[v])
+        emit({'sweep': 'default_wall_per_step', 'envs_per_wg': v[0], 'fuse_obs': v[1], 'block': v[2],
+              'wall_us_per_step': round(med, 2), 'agent_steps_per_s': round(b * (c + p) / med * 1e6)}, args.out)
+    env.close()
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('what', choices=['stress', 'default', 'wall'])
+    ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--out', default='')
+    a = ap.parse_args()
+    {'stress': stress, 'default': default, 'wall': wall}[a.what](a)
