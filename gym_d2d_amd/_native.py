@@ -25,7 +25,8 @@ OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
  BUF_REWARD, BUF_OBS_TABLE, BUF_OBS, BUF_ENV_FLAGS, BUF_COUNT) = range(14)
 FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
 (TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK, TUNE_OBS_VARIANT,
- TUNE_STEP_THREADS, TUNE_STEP_ENVS_PER_WG, TUNE_STEP_BLOCK, TUNE_STEP_VARIANT, TUNE_STEP_FUSE_OBS) = range(10)
+ TUNE_STEP_THREADS, TUNE_STEP_ENVS_PER_WG, TUNE_STEP_BLOCK, TUNE_STEP_VARIANT, TUNE_STEP_FUSE_OBS,
+ TUNE_STEP_ABLATE) = range(11)
 STEP_MASK_WALK, STEP_RB_SORTED = 0, 1
 UNIQUE_ID_BYTES = 128
 

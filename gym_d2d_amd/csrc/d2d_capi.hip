@@ -81,6 +81,7 @@ struct d2d_handle {
     std::vector<int> host_tx, host_rx, host_type;   // host copy of the link table
     std::vector<int> fixed_rb, fixed_pwr;            // per link; fixed_rb[i] == INT32_MIN <=> agent-driven
     int n_fixed = 0;
+    int col_mode = 0;                                // 0: fixed links form a prefix of the link list
     bool have_dev = false, have_pl = false, have_links = false, have_pos = false, tables_dirty = true;
     d2d::PlMode mode = d2d::PL_INV_SQUARE;
     int reward_fn = D2D_REWARD_SYSTEM_CAPACITY;
@@ -88,7 +89,7 @@ struct d2d_handle {
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
-    int tune_step_epw = 0, tune_step_block = 0, tune_step_variant = -1, tune_step_fuse = -1;
+    int tune_step_epw = 0, tune_step_block = 0, tune_step_variant = -1, tune_step_fuse = -1, tune_step_ablate = 0;
     // d2d_step_host: packed device block + pinned host mirrors
     void* host_out_dev = nullptr; size_t host_out_bytes = 0;
     void* host_out_pinned = nullptr;
@@ -165,14 +166,21 @@ int refresh_tables(d2d_handle* h) {
     int32_t* ra = reinterpret_cast<int32_t*>(rec.data());
     float* rb = rec.data() + (size_t)S * 4;
     float* rc = rec.data() + (size_t)2 * S * 4;
+    const int levels[4] = {0, h->cfg.pwr_levels_cue, h->cfg.pwr_levels_mbs, h->cfg.pwr_levels_due};   // by d2d_link_type
     int col = 0;
+    bool prefix = true;               // are the fixed links exactly the first n_fixed links?
     for (int i = 0; i < N; ++i) {
         const int t = h->host_tx[i], r = h->host_rx[i];
         const bool fixed = h->fixed_rb[i] != INT32_MIN;
         ra[4 * i + 0] = t | (h->host_type[i] << D2D_REC_TYPE_SHIFT) | (fixed ? D2D_REC_FIXED_BIT : 0);
         ra[4 * i + 1] = r;
-        ra[4 * i + 2] = fixed ? h->fixed_rb[i] : col++;
-        ra[4 * i + 3] = fixed ? h->fixed_pwr[i] : 0;
+        const uint32_t P = (uint32_t)levels[h->host_type[i]];
+        const uint64_t M = P < 512 ? ((1ull << 40) + P - 1) / P : 0ull;       // ceil(2^40 / P); 0 -> hardware divide
+        ra[4 * i + 2] = fixed ? h->fixed_rb[i] : (int32_t)(uint32_t)(M & 0xFFFFFFFFull);
+        ra[4 * i + 3] = fixed ? h->fixed_pwr[i] : (int32_t)(uint32_t)(M >> 32);
+        if (fixed != (i < h->n_fixed)) prefix = false;
+        const uint32_t packed = (P & 0xFFFFu) | ((uint32_t)(fixed ? 0 : col++) << 16);
+        std::memcpy(&rc[4 * i + 3], &packed, 4);
         rb[4 * i + 0] = cols[0 * D + t];    // tx_lin
         rb[4 * i + 1] = cols[1 * D + r];    // rx_pl
         rb[4 * i + 2] = cols[2 * D + r];    // rx_lin
@@ -183,6 +191,7 @@ int refresh_tables(d2d_handle* h) {
     }
     HIP_TRY(hipMemcpyAsync(h->rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // rec is a stack-lifetime host buffer
+    h->col_mode = prefix ? 0 : 1;
     h->tables_dirty = false;
     h->lpos_dirty = true;                       // the link -> device map may have changed
     return D2D_OK;
@@ -288,11 +297,13 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.B = h->B; s.N = N; s.R = h->cfg.num_rbs; s.D = D;
     s.action_mode = action_mode;
     s.act_stride = action_mode == 0 ? N - h->n_fixed : N;
-    s.p_due = h->cfg.pwr_levels_due; s.p_cue = h->cfg.pwr_levels_cue; s.p_mbs = h->cfg.pwr_levels_mbs;
-    auto magic = [](int P) -> unsigned long long { return P < 512 ? ((1ull << 40) + (unsigned)P - 1) / (unsigned)P : 0ull; };
-    s.m_due = magic(s.p_due); s.m_cue = magic(s.p_cue); s.m_mbs = magic(s.p_mbs);
+    s.col_mode = h->col_mode; s.n_fixed = h->n_fixed;
+    s.inv_n = 1.0f / (float)N;
+    if ((size_t)h->B * (size_t)N * 6 >= (1ull << 31))
+        return fail(D2D_ERR_UNSUPPORTED, "envs x links per GPU must stay below 2^31 / 6 (32-bit element offsets in the step kernel)");
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
+    s.ablate = h->tune_step_ablate;
 
     // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
     // workgroup (N = 50: four 64-thread envs in 256 threads), and for small N the LinearObs expansion runs inside the
@@ -323,6 +334,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     if (block < epw * tpe) block = epw * tpe;
     if (block > 1024) return fail(D2D_ERR_INVALID, "step workgroup exceeds 1024 threads");
     s.tpe = tpe; s.epw = epw; s.mask_words = W; s.fuse_obs = fuse;
+    s.tpe_magic = ((1u << 20) + (unsigned)tpe - 1) / (unsigned)tpe;
     // interferer search: the RB-sorted buckets need one link per thread and the masks (their ranks); see DESIGN.md 4.1
     // for the A/B that picked the default
     int variant = h->tune_step_variant >= 0 ? h->tune_step_variant : d2d::STEP_RB_SORTED;
@@ -702,6 +714,9 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
             if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "variant must be -1, 0 or 1");
             h->tune_step_variant = value;
             break;
+        case D2D_TUNE_STEP_ABLATE:
+            h->tune_step_ablate = value & 255;
+            break;
         case D2D_TUNE_STEP_FUSE_OBS:
             if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "fuse_obs must be -1, 0 or 1");
             h->tune_step_fuse = value;
@@ -813,7 +828,7 @@ int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const ui
 int d2d_step(d2d_handle* h, const int32_t* actions_dev) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
-    if (!actions_dev && !h->buf[D2D_BUF_ACTIONS].ptr && h->n_fixed < h->N)
+    if (!actions_dev && !h->buf[D2D_BUF_ACTIONS].ptr && (h->N == 0 || h->n_fixed < h->N))
         return fail(D2D_ERR_STATE, "no actions: pass a pointer or fill D2D_BUF_ACTIONS");
     return run_step(h, 0, actions_dev, nullptr, nullptr);
 }

@@ -22,10 +22,11 @@ enum StepVariant : int {
 // Per-link record, three 16-byte rows shared by all envs and read coalesced by link index (L2-resident).  Built on
 // the host from the per-device columns + the link table whenever links, tables or fixed actions change.
 //   a (int4)   x: tx device | link_type << 24 | fixed << 28     y: rx device
-//              z: fixed ? rb : column of this link in the raw action array       w: fixed ? tx power dBm : 0
+//              z, w: fixed ? (rb, tx power dBm) : (low, high word of the division magic ceil(2^40 / P), 0 = divide)
 //   b (float4) x: tx_lin = 10^((eirp_off - a_tx)/10)   y: rx_pl = 10^(-a_rx/10)   z: rx_lin = 10^(rx_off/10)
 //              w: noise_mw = 10^(thermal_noise_dBm/10)
-//   c (float4) x: rx_sensitivity_dBm   y: 1e-6 * RB bandwidth (Hz) of the tx   z: path-loss exponent of the tx   w: -
+//   c (float4) x: rx_sensitivity_dBm   y: 1e-6 * RB bandwidth (Hz) of the tx   z: path-loss exponent of the tx
+//              w: (bits) P = power levels of this link's type (d2d_env.py:31-35) | action column << 16
 #define D2D_REC_TXDEV_MASK 0x00FFFFFF
 #define D2D_REC_TYPE_SHIFT 24
 #define D2D_REC_TYPE_MASK 0xF
@@ -37,14 +38,17 @@ struct StepArgs {
     int mask_words;          // ceil(N/64): u64 words per RB membership mask (0 -> all-pairs path)
     int action_mode;         // 0: raw int actions (a // P, a % P)   1: explicit rb / pwr
     int act_stride;          // columns of the action array(s): N - n_fixed in mode 0, N in mode 1
-    int p_due, p_cue, p_mbs; // power levels per link type (d2d_env.py:31-35)
-    unsigned long long m_due, m_cue, m_mbs;   // ceil(2^40 / P) division magics (0 -> use the hardware divide)
+    int col_mode;            // 0: fixed links are exactly the first n_fixed links (column = link - n_fixed)   1: column from the record
+    int n_fixed;
     int tpe;                 // threads per env (multiple of 64, <= 1024)
+    unsigned tpe_magic;      // ceil(2^20 / tpe): tid / tpe == (tid * tpe_magic) >> 20 for tid < 1024
+    float inv_n;             // 1 / N
     int epw;                 // envs per workgroup (epw * tpe <= blockDim)
     int variant;             // StepVariant
     int reward_fn;
     float reward_param;
     int write_table;
+    int ablate;              // DIAGNOSTIC (D2D_TUNE_STEP_ABLATE): skip parts of the kernel to time the rest; results are wrong
     // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)
     int fuse_obs;
     unsigned obs_q_per_row;          // 6N / fuse_obs

@@ -47,9 +47,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LINK_DOWNLINK 2
 #define LINK_SIDELINK 3
 
+// DPP lane exchange (VALU, ~8 cycles) instead of ds_bpermute (LDS crossbar, > 100 cycles) for the in-row steps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 64 lanes, every lane receives the same bits: quad butterfly (xor 1, xor 2), half-row mirror, row mirror
+// (each lane adds its partner's partial: a + b == b + a), then the two cross-row steps.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += dpp_f32<0xB1>(v);          // quad_perm:[1,0,3,2]
+    v += dpp_f32<0x4E>(v);          // quad_perm:[2,3,0,1]
+    v += dpp_f32<0x141>(v);         // row_half_mirror
+    v += dpp_f32<0x140>(v);         // row_mirror
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 
@@ -164,47 +176,78 @@ __device__ __forceinline__ Smem carve(unsigned char* base, int N, int R, int W, 
     return s;
 }
 
-// Everything pass 1 needs about one link, in registers.
-struct LinkIn {
-    int type, txd, rxd, rb, p;
-    float4 pos;          // tx_x, tx_y, rx_x, rx_y
+// Everything the kernel needs about one link, as it comes out of memory.  The loads are INDEPENDENT of one another
+// (no link -> device -> position double hop, no power-table lookup, no per-type constant fetched behind the record):
+// they are issued back to back in the prologue and first used after pass 0's barrier.
+struct LinkRaw {
+    int4 ra;             // rec_a
     float4 rb_;          // rec_b: tx_lin, rx_pl, rx_lin, noise_mw
-    float4 rc;           // rec_c: sens_db, bw_mhz, exponent
+    float4 rc;           // rec_c: sens_db, bw_mhz, exponent, (P | column << 16)
+    float4 pos;          // tx_x, tx_y, rx_x, rx_y
+    int act0, act1;      // raw action, or explicit (rb, pwr)
 };
 
-// All five loads are independent of one another (no link -> device -> position double hop, no power-table lookup).
-__device__ __forceinline__ LinkIn load_link(const StepArgs& a, size_t row, size_t act_row, int i) {
-    LinkIn in;
-    const int4 ra = a.rec_a[i];
+__device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, unsigned act_row, int i) {
+    LinkRaw in;
+    in.act0 = 0; in.act1 = 0;
+    // actions first, branch-free per lane (uniform branches only), so that no join forces a wait on the loads in flight
+    if (a.action_mode == 0) {
+        if (a.col_mode == 0 && a.act_stride > 0) {
+            // fixed links are the first n_fixed links (the traffic-model case, CUE links first) or there are none: the
+            // action column follows from the link index alone, so this load does not wait for the record.  A fixed
+            // link reads column 0 and ignores it.
+            const int col = i - a.n_fixed;
+            in.act0 = a.actions[act_row + (unsigned)(col > 0 ? col : 0)];
+        }
+    } else {
+        in.act0 = a.rb_in[row + (unsigned)i];
+        in.act1 = a.pwr_in[row + (unsigned)i];
+    }
+    in.ra = a.rec_a[i];
     in.rb_ = a.rec_b[i];
     in.rc = a.rec_c[i];
-    in.pos = a.lpos[row + i];
-    in.type = (ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
-    in.txd = ra.x & D2D_REC_TXDEV_MASK;
-    in.rxd = ra.y;
-    if (ra.x & D2D_REC_FIXED_BIT) {
-        // a link driven by the traffic model (traffic_model.py:15-32): (rb, pwr) live in the record, agents do not
-        // supply an action for it.  No decode: any power is legal, as in the reference's Action(rb, pwr).
-        in.rb = ra.z; in.p = ra.w;
+    in.pos = a.lpos[row + (unsigned)i];
+    return in;
+}
+
+// (rb, tx power dBm) of a link: fixed by the traffic model (traffic_model.py:15-32), decoded from the raw action
+// (d2d_env.py:94-96, Python floor semantics; NB due_min_tx_power_dBm is not added back), or given explicitly.
+__device__ __forceinline__ void decode_link(const StepArgs& a, const LinkRaw& in, unsigned act_row, int& rb, int& p) {
+    if (in.ra.x & D2D_REC_FIXED_BIT) {
+        rb = in.ra.z; p = in.ra.w;            // no decode: any power is legal, as in the reference's Action(rb, pwr)
     } else if (a.action_mode == 0) {
-        // d2d_env.py:94-96 with Python floor semantics; NB due_min_tx_power_dBm is not added back
-        const int act = a.actions[act_row + ra.z];
-        const int P = in.type == LINK_SIDELINK ? a.p_due : (in.type == LINK_UPLINK ? a.p_cue : a.p_mbs);
+        int act = in.act0;
+        // arbitrary fixed sets (not a prefix of the link list): the action column comes from the record, so this one
+        // load is a dependent second hop - taken here, after pass 0, never in the prologue
+        if (a.col_mode != 0) act = a.actions[act_row + (__float_as_uint(in.rc.w) >> 16)];
+        const int P = (int)(__float_as_uint(in.rc.w) & 0xFFFFu);
+        const unsigned long long M = (unsigned long long)(unsigned)in.ra.z | ((unsigned long long)(unsigned)in.ra.w << 32);
         int q, r;
-        if (act >= 0) {
+        if (act >= 0 && M != 0ull) {
             // exact for 0 <= act < 2^31 and P < 2^9: q = floor(act * ceil(2^40 / P) / 2^40) (host-computed magic)
-            const unsigned long long M = in.type == LINK_SIDELINK ? a.m_due : (in.type == LINK_UPLINK ? a.m_cue : a.m_mbs);
-            q = M ? (int)(((unsigned long long)(unsigned)act * M) >> 40) : act / P;
+            q = (int)(((unsigned long long)(unsigned)act * M) >> 40);
             r = act - q * P;
         } else {
             q = act / P; r = act - q * P;
             if (r < 0) { r += P; q -= 1; }
         }
-        in.rb = q; in.p = r;
+        rb = q; p = r;
     } else {
-        in.rb = a.rb_in[row + i]; in.p = a.pwr_in[row + i];
+        rb = in.act0; p = in.act1;
     }
-    return in;
+}
+
+// x / y with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 VALU): 2e-7 relative.  Used where the
+// quotient's error is second order (the x / (u - 1) factor of log2(1 + x)).
+__device__ __forceinline__ float fast_div(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
+
+// x / y to within an ulp: v_rcp_f32 + one Newton step on the quotient (4 VALU instead of ~10; no denormal / overflow
+// special cases - the operands here are powers in mW, far from both).  The SINR / SNR quotients use this one: at
+// |value| < 1 dB the 1e-5 bar is 1e-5 dB absolute = 2.3e-6 relative, and the power-law modes need that headroom.
+__device__ __forceinline__ float precise_div(float x, float y) {
+    const float r = __builtin_amdgcn_rcpf(y);
+    const float q = x * r;
+    return fmaf(fmaf(-y, q, x), r, q);
 }
 
 // source float index inside T_flat for output column f (even) of row i (obs_fn.py:43-53: own link first, then the
@@ -223,41 +266,48 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int N = a.N, R = a.R, D = a.D, W = a.mask_words, TPE = a.tpe;
     const int tid = threadIdx.x;
-    const int e = tid / TPE, lt = tid - e * TPE;          // env slot in this workgroup (wave-uniform: TPE % 64 == 0)
+    // env slot in this workgroup (wave-uniform: TPE % 64 == 0); tid / TPE by multiply-shift, exact for tid < 1024
+    const int e = (int)(((unsigned)tid * a.tpe_magic) >> 20), lt = tid - e * TPE;
     const int b = blockIdx.x * a.epw + e;
     const bool active = e < a.epw && b < a.B;
-    const size_t row = (size_t)b * N;
-    const size_t act_row = (size_t)b * a.act_stride;
+    // element offsets fit 32 bits (the host refuses B * N * 6 >= 2^31): one VGPR offset + SGPR base per access
+    const unsigned row = (unsigned)b * (unsigned)N;
+    const unsigned act_row = (unsigned)b * (unsigned)a.act_stride;
     const size_t env_lds = lds_env_bytes(N, R, W, a.fuse_obs);
     Smem s = carve(smem_raw + (size_t)(e < a.epw ? e : 0) * env_lds, N, R, W, a.fuse_obs);
 
     // ---- prologue: issue this thread's link's loads BEFORE any LDS work or barrier, so their latency overlaps pass 0
-    LinkIn first;
-    if (active && lt < N) first = load_link(a, row, act_row, lt);
+    // Inactive lanes (lt >= N, spare env slots) load a clamped duplicate instead of branching around the loads: a
+    // join after conditional loads makes the compiler wait for all of them right here.
+    const unsigned b_ld = (a.ablate & 128) ? 0u : (unsigned)(active ? b : a.B - 1);   // 128: every env re-reads env 0 (L2)
+    const LinkRaw first = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, lt < N ? lt : N - 1);
 
     // ---- pass 0: clear masks and flags
-    const bool want_masks = W > 0;
+    const int abl = a.ablate;                 // diagnostic only (tools/ablate_step.py): bits skip parts of the kernel
+    const bool want_masks = W > 0 && !(abl & 4);
     if (active) {
         if (want_masks)
             for (int k = lt; k < R * W + W + (R + 1) / 2; k += TPE) s.mask[k] = 0ull;      // masks + per-RB words
         if (lt < 4) s.flags[lt] = 0;
         if (lt < 16) s.red[lt] = 0.0f;
     }
-    __syncthreads();
+    if (!(abl & 64)) __syncthreads();
 
     // ---- pass 1: decode + stage the transmitter side of every link
     float4 me0 = make_float4(0.f, 0.f, 0.f, 0.f);
     FOR_MY_LINKS(i) {
-        const LinkIn in = i == lt ? first : load_link(a, row, act_row, i);
-        const int rb = in.rb;
-        const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(in.p) * in.rb_.x, __int_as_float(rb));
+        const LinkRaw in = i == lt ? first : load_link(a, row, act_row, i);
+        int rb, p;
+        decode_link(a, in, act_row, rb, p);
+        const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
+        const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(p) * in.rb_.x, __int_as_float(rb));
         if (!SORTED) s.link[i] = tuple;
-        s.rx[i] = make_float2(in.pos.z, in.pos.w);
-        s.aux[i] = in.txd | (in.type << 24);
+        if (!SINGLE) s.rx[i] = make_float2(in.pos.z, in.pos.w);
+        s.aux[i] = in.ra.x & 0x0FFFFFFF;                                 // tx_dev | link_type << 24
         if (i == lt) me0 = tuple;                                        // own link stays in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
-        if (a.rb_out) { a.rb_out[row + i] = rb; a.pwr_out[row + i] = in.p; }
-        if (want_masks) {
+        if (a.rb_out && !(abl & 32)) { a.rb_out[row + (unsigned)i] = rb; a.pwr_out[row + (unsigned)i] = p; }
+        if (want_masks && !(abl & 2)) {
             const u64 bit = 1ull << (i & 63);
             if ((unsigned)rb < (unsigned)R) {
                 atomicOr(&s.mask[(size_t)(i >> 6) * R + rb], bit);
@@ -265,11 +315,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 else atomicOr(&s.rbinfo[rb], 1u << (i >> 6));
             }
             else atomicOr(&s.flags[0], FLAG_RB_OOR);
-            if (in.type == LINK_SIDELINK) atomicOr(&s.mask[(size_t)R * W + (i >> 6)], bit);
+            if (type == LINK_SIDELINK) atomicOr(&s.mask[(size_t)R * W + (i >> 6)], bit);
         }
     }
-    __syncthreads();
+    if (!(abl & 64)) __syncthreads();
     const bool use_masks = want_masks && active && !(s.flags[0] & FLAG_RB_OOR);
+    const bool skip_walk = (abl & 7) != 0;
 
     // ---- pass 1b (STEP_RB_SORTED): stable counting sort of the transmitter tuples by RB.
     //   rank of link i inside its bucket = number of lower-indexed members = popcount of the mask bits below i;
@@ -307,7 +358,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             if (use_masks) {
                 const unsigned se = s.rbinfo[__float_as_int(me0.w)];
                 s.link[(se & 0xFFFFu) + my_rank] =
-                    make_float4(me0.x, me0.y, me0.z, __int_as_float(lt | (first.type << 16)));
+                    make_float4(me0.x, me0.y, me0.z, __int_as_float(lt | (((first.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK) << 16)));
             } else {
                 s.link[lt] = me0;                                        // all-pairs fallback: by link index, .w = rb
             }
@@ -323,17 +374,19 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     int my_flags = 0;
     bool violated = false;
     FOR_MY_LINKS(i) {
-        const LinkIn in = i == lt ? first : load_link(a, row, act_row, i);   // strided links: records re-read (L2)
+        const LinkRaw in = i == lt ? first : load_link(a, row, act_row, i);   // strided links: records re-read (L2)
         const float4 me = i == lt ? me0 : s.link[i];
         const float2 rx = make_float2(in.pos.z, in.pos.w);
-        const int rb = i == lt ? __float_as_int(me0.w) : in.rb;
-        const int txd = in.txd, rxd = in.rxd;
+        const int rb = __float_as_int(me.w);
+        const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
+        const int txd = in.ra.x & D2D_REC_TXDEV_MASK, rxd = in.ra.y;
         const float rx_pl = in.rb_.y, rx_lin = in.rb_.z, noise = in.rb_.w;
         const float sens = in.rc.x, bw_mhz = in.rc.y;
         float acc = 0.0f;
-        bool zero = false;
+        float dmin = 3.0e38f;                                            // smallest squared distance met: 0 <=> 'math domain error'
 
-        if (SORTED && use_masks) {
+        if (skip_walk) {
+        } else if (SORTED && use_masks) {
             const unsigned se = s.rbinfo[rb];
             const int st = (int)(se & 0xFFFFu), cnt = (int)(se >> 16);       // cnt >= 1: this link itself
             for (int k0 = 0; k0 < cnt; k0 += 4) {
@@ -349,7 +402,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     const float d2 = fmaf(dx, dx, dy * dy);
                     float g;
                     if (MODE == PL_TABLE) g = use ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
-                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); zero |= use & (d2 == 0.0f); }
+                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = fminf(dmin, use ? d2 : dmin); }
                     if (MODE == PL_SHADOW && use && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                     acc = use ? fmaf(o[u].z, g, acc) : acc;                         // simulator.py:97-101, linear mW
                 }
@@ -370,7 +423,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     const float d2 = fmaf(dx, dx, dy * dy);
                     float g;
                     if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
-                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); zero |= d2 == 0.0f; }
+                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = fminf(dmin, d2); }
                     if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                     acc = fmaf(o.z, g, acc);                             // simulator.py:97-101, linear mW
                 }
@@ -384,7 +437,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
-                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); zero |= same & (d2 == 0.0f); }
+                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = fminf(dmin, same ? d2 : dmin); }
                 if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                 acc = same ? fmaf(o.z, g, acc) : acc;
             }
@@ -395,7 +448,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
-        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); zero |= d2 == 0.0f; }
+        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); dmin = fminf(dmin, d2); }
         float sig = me.z * g * rx_pl * rx_lin;                           // mW at the receiver, with rx gains
         float sig_snr = sig;
         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
@@ -403,25 +456,27 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             sig *= shadow_factor(a, genv, i, i, 0u);                     // simulator.py:93
         }
         const float ix = acc * rx_pl;                                    // interferers: no rx gains (simulator.py:100)
-        const float sinr_lin = sig / (ix + noise);
+        const float sinr_lin = precise_div(sig, ix + noise);
         // dB = 10 log10 x = 3.0103 log2 x, log2 on the transcendental unit (v_log_f32, 1 ulp): abs error < 6e-6 dB
         // at 80 dB and < 1e-6 dB near 0 dB, inside the 1e-5 * max(|ref|, 1) bar with an order of magnitude to spare
         const float sinr_db = 3.01029995663981195f * __builtin_amdgcn_logf(sinr_lin);         // simulator.py:106-107
-        const float snr_db = 3.01029995663981195f * __builtin_amdgcn_logf(sig_snr / noise);   // simulator.py:115
+        const float snr_db = 3.01029995663981195f * __builtin_amdgcn_logf(precise_div(sig_snr, noise));   // simulator.py:115
         // log2(1 + x) without losing small x: log2(u) * x / (u - 1), u = fl(1 + x)
         const float u1p = 1.0f + sinr_lin, um1 = u1p - 1.0f;
         const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f
-                                     : __builtin_amdgcn_logf(u1p) * (sinr_lin / um1);
+                                     : __builtin_amdgcn_logf(u1p) * fast_div(sinr_lin, um1);
         const bool ok = sinr_db > sens;                                  // simulator.py:123,149
         const float rate = ok ? sh : 0.0f;
         const float cap = ok ? bw_mhz * sh : 0.0f;                       // simulator.py:150-151
 
-        a.sinr_db[row + i] = sinr_db;
-        a.snr_db[row + i] = snr_db;
-        a.rate[row + i] = rate;
-        a.cap[row + i] = cap;
-        if (a.write_table) {                                             // obs_fn.py:57-60
-            float2* t = reinterpret_cast<float2*>(a.table + (row + i) * 6);
+        if (!(abl & 8)) {
+            a.sinr_db[row + (unsigned)i] = sinr_db;
+            a.snr_db[row + (unsigned)i] = snr_db;
+            a.rate[row + (unsigned)i] = rate;
+            a.cap[row + (unsigned)i] = cap;
+        }
+        if (a.write_table && !(abl & 16)) {                              // obs_fn.py:57-60
+            float2* t = reinterpret_cast<float2*>(a.table) + (row + (unsigned)i) * 3u;
             t[0] = make_float2(me.x, me.y);
             t[1] = rx;
             t[2] = make_float2(sinr_db, snr_db);
@@ -438,7 +493,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             // SystemCapacityRewardFunction's -1 rule (reward_fn.py:29-41), from this link's side: I am a non-D2D
             // link whose capacity is <= min_capacity and some D2D link shares my RB.  Masks / tuples of ALL links
             // were published by the barrier before this pass, so no further synchronisation is needed here.
-            if (in.type != LINK_SIDELINK && cap <= a.reward_param) {
+            if (type != LINK_SIDELINK && cap <= a.reward_param) {
                 bool hit = false;
                 if (use_masks) {
                     for (int w = 0; w < W; ++w)
@@ -451,7 +506,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             }
         }
         cap_part += cap;
-        if (zero) my_flags |= FLAG_ZERO_DISTANCE;
+        if (dmin == 0.0f) my_flags |= FLAG_ZERO_DISTANCE;
         if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
     }
     if (my_flags) atomicOr(&s.flags[0], my_flags);
@@ -468,18 +523,18 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             const float4* red4 = reinterpret_cast<const float4*>(s.red);       // 16 slots, zero-padded: fixed-order sum
             float total = 0.0f;
             for (int w = 0; w < (TPE + 255) >> 8; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
-            const float r = s.flags[1] ? -1.0f : total / (float)N;
-            FOR_MY_LINKS(i) a.reward[row + i] = r;
+            const float r = s.flags[1] ? -1.0f : total * a.inv_n;
+            FOR_MY_LINKS(i) a.reward[row + (unsigned)i] = r;
         }
     } else if (a.reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57
-        FOR_MY_LINKS(i) a.reward[row + i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
+        FOR_MY_LINKS(i) a.reward[row + (unsigned)i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
         __syncthreads();
     } else if (a.reward_fn == 3) {
         // CueSinrShannonRewardFunction, reward_fn.py:65-78
         __syncthreads();
         FOR_MY_LINKS(i) {
-            const int rbi = i == lt ? __float_as_int(me0.w) : load_link(a, row, act_row, i).rb;
+            const int rbi = i == lt ? __float_as_int(me0.w) : __float_as_int(s.link[i].w);
             bool bad = false;
             if (SORTED && use_masks) {
                 const unsigned se = s.rbinfo[rbi];
@@ -506,7 +561,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     bad |= (j != i) & ((s.aux[j] >> 24) != LINK_SIDELINK) & (__float_as_int(s.link[j].w) == rbi) &
                            (s.sinr[j] < a.reward_param);
             }
-            a.reward[row + i] = bad ? -1.0f : s.sh[i];
+            a.reward[row + (unsigned)i] = bad ? -1.0f : s.sh[i];
         }
         __syncthreads();
     } else {

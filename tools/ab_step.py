@@ -64,6 +64,32 @@ def stress(args):
     env.close()
 
 
+def ablate(args):
+    """Diagnostic builds of the same kernel with parts skipped (D2D_TUNE_STEP_ABLATE): where the time goes."""
+    b, c, p, r = 4096, 256, 256, 256
+    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
+    env.reset(seed=1)
+    h = env.simulator.handle
+    act = env.action_buffer()
+    names = {0: 'full', 1: '-walk', 3: '-walk -mask_build', 7: '-walk -mask_build -mask_clear', 8: '-result_stores',
+             16: '-table_store', 32: '-rb_pwr_stores', 56: '-all_stores', 63: 'loads + decode + math only',
+             63 + 64: 'loads + decode + math only, no pass-0/1 barriers', 63 + 128: 'math only: per-env loads hit L2 (env 0)',
+             63 + 192: 'math only, L2 loads, no pass-0/1 barriers', 128: 'full, but per-env loads hit L2 (env 0)'}
+    variants = [(rw, var, ab) for rw in (1, 0) for var in ((0, 1) if args.both else (0,)) for ab in names]
+    times = {v: [] for v in variants}
+    for rnd in range(args.rounds):
+        for v in variants:
+            h.set_reward(v[0], 0.0)
+            h.set_tuning(_native.TUNE_STEP_VARIANT, v[1])
+            h.set_tuning(_native.TUNE_STEP_ABLATE, v[2])
+            times[v].append(timed(h, act, 10))
+    h.set_tuning(_native.TUNE_STEP_ABLATE, 0)
+    for v in variants:
+        emit({'sweep': 'stress_ablation', 'reward_fn': v[0], 'variant': v[1], 'skipped': names[v[2]],
+              'median_us': round(statistics.median(times[v]), 2)}, args.out)
+    env.close()
+
+
 def default(args):
     b, c, p, r = 1024, 25, 25, 25
     env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': LinearObsFunction}, num_envs=b,
@@ -121,8 +147,9 @@ def wall(args):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['stress', 'default', 'wall'])
+    ap.add_argument('what', choices=['stress', 'default', 'wall', 'ablate'])
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--out', default='')
+    ap.add_argument('--both', action='store_true', help='ablate: both interferer-search variants')
     a = ap.parse_args()
-    {'stress': stress, 'default': default, 'wall': wall}[a.what](a)
+    {'stress': stress, 'default': default, 'wall': wall, 'ablate': ablate}[a.what](a)
