@@ -49,8 +49,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_chunk(job):
-    """One worker's share of the CPU baseline: `calls` oracle steps of `envs` envs each (module-level: picklable)."""
-    c, p, r, envs, calls, seed = job
+    """One worker's share of the CPU baseline: oracle steps of `envs` envs each until `calls` calls are done or the
+    wall-clock `deadline` (time.time()) has passed, whichever comes first (module-level: picklable)."""
+    c, p, r, envs, calls, seed, deadline = job
     for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
         os.environ[var] = '1'
     from oracle import d2d_oracle as orc
@@ -62,24 +63,24 @@ def _cpu_chunk(job):
     tx, rx, ty = default_links(c, p)
     pos = random_layout(rng, envs, c, p).astype(np.float64)
     t0 = time.perf_counter()
-    for _ in range(calls):
+    done = 0
+    while done < calls and (done == 0 or time.time() < deadline):
         raw = np.concatenate([rng.integers(0, r * 24, (envs, c)), rng.integers(0, r * 21, (envs, p))], 1)
         orc.full_step(pos, tx, rx, ty, raw, cols, orc.PathLossSpec(), with_obs=True, chunk=envs)
-    return envs * calls, time.perf_counter() - t0
+        done += 1
+    return envs * done, time.perf_counter() - t0
 
 
-def cpu_baseline(w, seconds_budget=10.0):
+def cpu_baseline(w, seconds_budget=16.0):
     """Time the NumPy fp64 oracle (a port of the reference's algorithm; the Python reference cannot travel to this
     box) on a bounded sample of the same workload, including the materialised LinearObs: one thread (`value`), and a
-    process pool over env chunks on every core this process may run on (`all_cores`).  Runs BEFORE this process
-    initialises HIP, so forking workers is safe."""
+    process pool over env chunks on every core this process may run on (`all_cores`).  Both legs are bounded by
+    wall-clock deadlines (about seconds_budget in total).  Runs BEFORE this process initialises HIP, so forking workers
+    is safe."""
     c, p, r = w['cues'], w['dues'], w['rbs']
     n = c + p
     envs = 8 if n > 100 else 128
-    # -- one thread: calibrate, then run ~seconds_budget/2
-    done, dt = _cpu_chunk((c, p, r, envs, 1, 1234))
-    calls = max(1, min(512, int(0.5 * seconds_budget / max(dt, 1e-3))))
-    done, dt = _cpu_chunk((c, p, r, envs, calls, 1234))
+    done, dt = _cpu_chunk((c, p, r, envs, 1 << 30, 1234, time.time() + 0.4 * seconds_budget))
     single = done * n / dt
     out = {'value': single, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
            'sample': f'{done} env-steps of the same workload ({done * n} agent-steps, obs materialised), '
@@ -89,16 +90,16 @@ def cpu_baseline(w, seconds_budget=10.0):
     try:
         import multiprocessing as mp
         cores = len(os.sched_getaffinity(0))
-        per_call = dt / calls
-        calls_each = max(1, int(0.4 * seconds_budget / max(per_call, 1e-3)))
-        t0 = time.perf_counter()
         with mp.get_context('fork').Pool(cores) as pool:
-            res = pool.map(_cpu_chunk, [(c, p, r, envs, calls_each, 1000 + k) for k in range(cores)], chunksize=1)
-        wall = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            deadline = time.time() + 0.4 * seconds_budget
+            res = pool.map(_cpu_chunk, [(c, p, r, envs, 1 << 30, 1000 + k, deadline) for k in range(cores)], chunksize=1)
+            wall = time.perf_counter() - t0
         total = sum(d for d, _ in res)
         out['all_cores'] = {'value': total * n / wall, 'unit': 'agent-steps/s', 'cores': cores,
                             'sample': f'{total} env-steps over {cores} worker processes (one per core, 1 NumPy/BLAS thread '
-                                      f'each, {envs} envs per oracle call), {wall:.1f} s wall incl. pool start'}
+                                      f'each, {envs} envs per oracle call, each worker runs until a shared deadline), '
+                                      f'{wall:.1f} s wall'}
     except Exception as exc:                      # pragma: no cover - a baseline failure must not lose the GPU number
         out['all_cores'] = {'error': repr(exc)}
     return out
@@ -204,7 +205,7 @@ def parse_args(argv=None):
     ap.add_argument('--with-reset', action='store_true', help='redraw all device positions every 10 steps (device-side reset)')
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
     ap.add_argument('--single-env-latency', action='store_true', help='also time the drop-in D2DEnv.step (host dicts), N = 1 only')
-    ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,variant,fuse')
+    ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,fuse')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST HOOK: no GPU, gloo backend, synthetic per-rank results - exercises only the launcher / gather plumbing')
     return ap.parse_args(argv)
@@ -278,7 +279,7 @@ def worker(args):
         tune_keys = {'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
                      'xcd': _native.TUNE_OBS_XCD_REMAP, 'block': _native.TUNE_OBS_BLOCK,
                      'threads': _native.TUNE_STEP_THREADS, 'epw': _native.TUNE_STEP_ENVS_PER_WG,
-                     'sblock': _native.TUNE_STEP_BLOCK, 'variant': _native.TUNE_STEP_VARIANT, 'fuse': _native.TUNE_STEP_FUSE_OBS}
+                     'sblock': _native.TUNE_STEP_BLOCK, 'fuse': _native.TUNE_STEP_FUSE_OBS}
         for kv in filter(None, args.tune.split(',')):
             k, v = kv.split('=')
             if k == 'bucket':

@@ -20,6 +20,14 @@ class Action:
     tx_pwr_dBm: float       # transmit power before antenna gains / losses
 
 
+def make_action(tx: Device, rx: Device, link_type: LinkType, rb: int, tx_pwr_dBm) -> Action:
+    """Action(tx, rx, link_type, rb, tx_pwr_dBm) without the five object.__setattr__ calls a frozen dataclass's
+    __init__ makes (the per-step cost of the single-env API is ~N of these)."""
+    act = object.__new__(Action)
+    object.__setattr__(act, '__dict__', {'tx': tx, 'rx': rx, 'link_type': link_type, 'rb': rb, 'tx_pwr_dBm': tx_pwr_dBm})
+    return act
+
+
 class Actions(UserDict):
     """{(tx_id, rx_id): Action}; insertion order is the agent order of every output.  Keeps a per-RB index that is
     built on first use and dropped by clear()."""

@@ -89,7 +89,7 @@ struct d2d_handle {
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
-    int tune_step_epw = 0, tune_step_block = 0, tune_step_variant = -1, tune_step_fuse = -1, tune_step_ablate = 0;
+    int tune_step_epw = 0, tune_step_block = 0, tune_step_fuse = -1, tune_step_ablate = 0, tune_step_walk = -1;
     // d2d_step_host: packed device block + pinned host mirrors
     void* host_out_dev = nullptr; size_t host_out_bytes = 0;
     void* host_out_pinned = nullptr;
@@ -304,6 +304,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
     s.ablate = h->tune_step_ablate;
+    s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : 0;
 
     // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
     // workgroup (N = 50: four 64-thread envs in 256 threads), and for small N the LinearObs expansion runs inside the
@@ -318,12 +319,14 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         const bool want = h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128;
         if (want) fuse = (6 * N) % 4 == 0 ? 4 : 2;
     }
+    // per-RB membership masks: u32 words, one link per thread (N <= 1024: the summary word names up to 32 mask words)
     int W = 0;
-    if (h->bucketing) {
-        W = (N + 63) / 64;
+    if (h->bucketing && single) {
+        W = (N + 31) / 32;
         if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse) > 96 * 1024) W = 0;
     }
-    const size_t env_lds = d2d::step_lds_bytes_per_env(N, s.R, W, fuse);
+    d2d::step_lds_layout(N, s.R, W, fuse, &s.off_mask, &s.lds_env);
+    const size_t env_lds = s.lds_env;
     if (env_lds > 160 * 1024) return fail(D2D_ERR_UNSUPPORTED, "links per env exceed the LDS staging capacity");
     int epw = h->tune_step_epw;
     if (epw <= 0) epw = tpe >= 256 ? 1 : 256 / tpe;
@@ -335,11 +338,6 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     if (block > 1024) return fail(D2D_ERR_INVALID, "step workgroup exceeds 1024 threads");
     s.tpe = tpe; s.epw = epw; s.mask_words = W; s.fuse_obs = fuse;
     s.tpe_magic = ((1u << 20) + (unsigned)tpe - 1) / (unsigned)tpe;
-    // interferer search: the RB-sorted buckets need one link per thread and the masks (their ranks); see DESIGN.md 4.1
-    // for the A/B that picked the default
-    int variant = h->tune_step_variant >= 0 ? h->tune_step_variant : d2d::STEP_RB_SORTED;
-    if (!single || W == 0 || N > 65535) variant = d2d::STEP_MASK_WALK;
-    s.variant = variant;
     if (fuse) {
         s.obs_q_per_row = (unsigned)(6 * N / fuse);
         s.obs_q_magic = ((1ull << 40) + s.obs_q_per_row - 1) / s.obs_q_per_row;
@@ -710,13 +708,18 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
             if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "block must be a multiple of 64 in [64,1024]");
             h->tune_step_block = value;
             break;
-        case D2D_TUNE_STEP_VARIANT:
-            if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "variant must be -1, 0 or 1");
-            h->tune_step_variant = value;
+        case D2D_TUNE_STEP_WALK:
+            if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "walk must be -1, 0 or 1");
+            h->tune_step_walk = value;
             break;
         case D2D_TUNE_STEP_ABLATE:
+#if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
             h->tune_step_ablate = value & 255;
             break;
+#else
+            if (value != 0) return fail(D2D_ERR_UNSUPPORTED, "D2D_TUNE_STEP_ABLATE needs the diagnostic build (D2D_BUILD_DIAG=1 python -m gym_d2d_amd.build)");
+            break;
+#endif
         case D2D_TUNE_STEP_FUSE_OBS:
             if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "fuse_obs must be -1, 0 or 1");
             h->tune_step_fuse = value;

@@ -13,12 +13,6 @@ enum PlMode : int {
     PL_SHADOW = 3        // PL_POWER + log-normal shadowing beyond d0, fresh Philox Gaussian per evaluation
 };
 
-// How same-RB interferers are found (results are bit-identical; d2d_set_tuning(D2D_TUNE_STEP_VARIANT)).
-enum StepVariant : int {
-    STEP_MASK_WALK = 0,  // per-RB membership bitmasks, walked with ctz (summary word -> mask word -> tuple)
-    STEP_RB_SORTED = 1   // stable counting sort by RB (mask popcount ranks + wave scan), contiguous bucket reads
-};
-
 // Per-link record, three 16-byte rows shared by all envs and read coalesced by link index (L2-resident).  Built on
 // the host from the per-device columns + the link table whenever links, tables or fixed actions change.
 //   a (int4)   x: tx device | link_type << 24 | fixed << 28     y: rx device
@@ -35,7 +29,9 @@ enum StepVariant : int {
 struct StepArgs {
     // geometry
     int B, N, R, D;
-    int mask_words;          // ceil(N/64): u64 words per RB membership mask (0 -> all-pairs path)
+    int mask_words;          // ceil(N/32): u32 words per RB membership mask (0 -> all-pairs path)
+    unsigned lds_env;        // LDS bytes per env and byte offset of the mask region inside it (step_lds_layout)
+    unsigned off_mask;
     int action_mode;         // 0: raw int actions (a // P, a % P)   1: explicit rb / pwr
     int act_stride;          // columns of the action array(s): N - n_fixed in mode 0, N in mode 1
     int col_mode;            // 0: fixed links are exactly the first n_fixed links (column = link - n_fixed)   1: column from the record
@@ -44,11 +40,11 @@ struct StepArgs {
     unsigned tpe_magic;      // ceil(2^20 / tpe): tid / tpe == (tid * tpe_magic) >> 20 for tid < 1024
     float inv_n;             // 1 / N
     int epw;                 // envs per workgroup (epw * tpe <= blockDim)
-    int variant;             // StepVariant
+    int walk;                // mask walk loop shape: 0 nested (words outside, members inside), 1 flattened
     int reward_fn;
     float reward_param;
     int write_table;
-    int ablate;              // DIAGNOSTIC (D2D_TUNE_STEP_ABLATE): skip parts of the kernel to time the rest; results are wrong
+    int ablate;              // DIAGNOSTIC builds only (-DD2D_STEP_ABLATE=1): skip parts of the kernel to time the rest
     // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)
     int fuse_obs;
     unsigned obs_q_per_row;          // 6N / fuse_obs
@@ -100,6 +96,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream);
 size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs);
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, unsigned* off_mask, unsigned* env_bytes);
 hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);
 hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const int4* rec_a, int B, int N, int D,
                                  float4* lpos, hipStream_t stream);

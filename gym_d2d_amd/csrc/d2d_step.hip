@@ -21,12 +21,18 @@
 //     second hop;
 //   * every link's transmitter tuple (tx_x, tx_y, effective tx power in mW, rb | index) is staged in LDS as a float4,
 //     so the interference loop is one ds_read_b128 per candidate interferer;
-//   * same-RB interferers (Actions.get_actions_by_rb) are found through per-RB membership bitmasks in LDS (built with
-//     ds_or_b64 - order independent), then either walked directly in ascending link order with ctz
-//     (STEP_MASK_WALK), or used as the ranks of a STABLE counting sort by RB (popcount of the lower bits = rank in the
-//     bucket, wave scan of the per-RB counts = bucket start) so that a receiver streams one contiguous LDS segment
-//     (STEP_RB_SORTED).  A masked all-pairs sweep is the fallback (rb outside [0,R), or mask table too large).  All
-//     three visit interferers in ascending link index through the same fmaf, hence produce identical bits;
+//   * same-RB interferers (Actions.get_actions_by_rb) are found through per-RB membership bitmasks in LDS
+//     (R x ceil(N/32) u32 words built with ds_or_b32 - order independent - plus one summary word per RB naming its
+//     non-empty words) and walked in ascending link order with ctz in ONE flattened loop (a lane either fetches its
+//     next non-empty word or consumes a member).  A masked all-pairs sweep is the fallback (rb outside [0,R), N > 1024,
+//     or mask table too large).  Both visit interferers in ascending link index through the same fmaf, hence produce
+//     identical bits.  The stable counting sort by RB that north_star suggests (mask-popcount ranks + a wave scan of the
+//     per-RB counts, each receiver then streaming one contiguous LDS segment) was built and measured in round 2: its
+//     walk is cheaper (3.8 vs 8.3 us at 4096 x 512) but rank + scan + scatter + two more barriers cost 7 us, 40.0 vs
+//     35.3 us overall (profiles/r2_ab_step_variants_stress.jsonl, commit 'A/B evidence'); the bitmask walk stayed;
+//   * the kernel is bound by instruction issue (scalar pipe: one SALU per cycle per CU) and LDS bank conflicts, not by
+//     HBM latency (profiles/r2_ablation_step_kernel_stress.jsonl): the FULL specialisation (every lane owns a link, one
+//     env per workgroup) carries no lane predication, the LDS layout is computed on the host, and loops are flat;
 //   * all arithmetic is in the LINEAR domain (mW): sinr = S / (I + N) with one 10*log10 at the end; the literal
 //     dB-domain transcription cannot hold 1e-5 relative in fp32 (hard parts);
 //   * reductions (capacity sum) are xor-butterfly wave reductions + a fixed-order cross-wave sum:
@@ -122,57 +128,48 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
     return exp2f(-0.33219280948873623f * a.shadow_chi * z);                     // 10^(-chi z / 10)
 }
 
-// LDS carve-up of ONE env.  80 bytes + 40 bytes per link + masks (+ 24 bytes per link when the obs expansion is fused).
-struct Smem {
-    float* red;     // [16] wave partial sums of this env (first: 16-byte aligned for the float4 reads of the reduction)
-    int* flags;     // [4]  0: env flags  1: reward violated
-    float4* link;   // [N] tx_x, tx_y, effective tx power (mW, incl. tx side of the PL constant), rb bits
-                    //     (STEP_RB_SORTED: in bucket order, .w = link index | link_type << 16)
-    float2* rx;     // [N] rx_x, rx_y
-    float* sinr;    // [N] sinr_db
-    float* sh;      // [N] log2(1 + sinr_lin)
-    float* expo;    // [N] path-loss exponent of the tx
-    int* aux;       // [N] tx_dev | link_type << 24
-    float* tflat;   // [6N] obs base table of this env (fused expansion only)
-    u64* mask;      // [W][R] per-RB membership (word-major: lanes with different RBs hit different banks), then [W] sidelink membership
-    unsigned* rbinfo; // [R] MASK_WALK: bit w set <=> mask[w][rb] != 0 (lets a receiver skip the empty words of its RB)
-                      //     RB_SORTED: member count, then bucket start | count << 16
-};
+// LDS layout of ONE env (byte offsets; the host computes lds_env / off_mask, see step_lds_layout):
+//   0    red[16] f32   wave partial sums            64   flags[4] i32   0: env flags  1: reward violated
+//   80   link[N] float4  tx_x, tx_y, effective tx power (mW, incl. tx side of the PL constant), rb bits
+//   +16N rx[N] float2 (strided links only)   +24N sinr[N]   +28N sh[N]   +32N expo[N]   +36N aux[N] (tx_dev | type << 24)
+//   +40N tflat[6N] f32 (fused obs expansion only)
+//   off_mask: mask[W][R] u32 per-RB membership, word-major (lanes with different RBs hit different banks),
+//             side[W] u32 sidelink membership, summ[R] u32 (bit w set <=> mask[w][rb] != 0)
+#define LDS_HEAD_BYTES 80u
 
-#define LDS_HEAD_BYTES 80        /* red[16] + flags[4] */
-#define LDS_TFLAT_OFFSET(N) (LDS_HEAD_BYTES + (size_t)(N) * 40)
-
-__host__ __device__ __forceinline__ size_t lds_fixed_bytes(int N, int fuse_obs) {
-    size_t bytes = LDS_TFLAT_OFFSET(N);
-    if (fuse_obs) bytes += (size_t)N * 24;
-    return (bytes + 7) & ~(size_t)7;
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, unsigned* off_mask, unsigned* env_bytes) {
+    unsigned bytes = LDS_HEAD_BYTES + (unsigned)N * 40u + (fuse_obs ? (unsigned)N * 24u : 0u);
+    bytes = (bytes + 7u) & ~7u;
+    *off_mask = bytes;
+    if (mask_words > 0) bytes += ((unsigned)R * mask_words + mask_words + (unsigned)R) * 4u;
+    *env_bytes = (bytes + 15u) & ~15u;
 }
 
 size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs) {
-    size_t bytes = lds_fixed_bytes(N, fuse_obs);
-    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words + (size_t)(R + 1) / 2) * 8;   // masks + per-RB words
-    return (bytes + 15) & ~(size_t)15;
+    unsigned off, bytes;
+    step_lds_layout(N, R, mask_words, fuse_obs, &off, &bytes);
+    return bytes;
 }
 
-__device__ __forceinline__ size_t lds_env_bytes(int N, int R, int mask_words, int fuse_obs) {
-    size_t bytes = lds_fixed_bytes(N, fuse_obs);
-    if (mask_words > 0) bytes += ((size_t)R * mask_words + mask_words + (size_t)(R + 1) / 2) * 8;
-    return (bytes + 15) & ~(size_t)15;
-}
+struct Smem {
+    float* red; int* flags; float4* link; float2* rx; float* sinr; float* sh; float* expo; int* aux; float* tflat;
+    unsigned* mask; unsigned* side; unsigned* summ;
+};
 
-__device__ __forceinline__ Smem carve(unsigned char* base, int N, int R, int W, int fuse_obs) {
+__device__ __forceinline__ Smem carve(unsigned char* base, unsigned N, unsigned R, unsigned W, unsigned off_mask) {
     Smem s;
     s.red = reinterpret_cast<float*>(base);
-    s.flags = reinterpret_cast<int*>(s.red + 16);
+    s.flags = reinterpret_cast<int*>(base + 64);
     s.link = reinterpret_cast<float4*>(base + LDS_HEAD_BYTES);
-    s.rx = reinterpret_cast<float2*>(s.link + N);
-    s.sinr = reinterpret_cast<float*>(s.rx + N);
-    s.sh = s.sinr + N;
-    s.expo = s.sh + N;
-    s.aux = reinterpret_cast<int*>(s.expo + N);
-    s.tflat = reinterpret_cast<float*>(base + LDS_TFLAT_OFFSET(N));
-    s.mask = reinterpret_cast<u64*>(base + lds_fixed_bytes(N, fuse_obs));
-    s.rbinfo = reinterpret_cast<unsigned*>(s.mask + (size_t)R * W + W);
+    s.rx = reinterpret_cast<float2*>(base + LDS_HEAD_BYTES + 16u * N);
+    s.sinr = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 24u * N);
+    s.sh = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 28u * N);
+    s.expo = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 32u * N);
+    s.aux = reinterpret_cast<int*>(base + LDS_HEAD_BYTES + 36u * N);
+    s.tflat = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 40u * N);
+    s.mask = reinterpret_cast<unsigned*>(base + off_mask);
+    s.side = s.mask + R * W;
+    s.summ = s.side + W;
     return s;
 }
 
@@ -258,40 +255,46 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
 }
 
 // SINGLE = every thread owns at most one link (N <= tpe, the normal case up to 1024 links): the per-link loops
-// collapse to a single predicated body, which removes their exec-mask bookkeeping from the scalar pipe.
-#define FOR_MY_LINKS(i) for (int i = lt, go_ = 1; go_ && active && i < N; i += TPE, go_ = !SINGLE)
+//          collapse to a single body.
+// FULL   = SINGLE, one env per workgroup and N == blockDim: every lane owns exactly one link of an existing env, so
+//          no lane predication (exec-mask save / restore on the scalar pipe) is generated anywhere outside the walk.
+#define FOR_MY_LINKS(i) for (int i = lt, go_ = 1; go_ && (FULL || (active && i < N)); i += TPE, go_ = !SINGLE)
 
-template <int MODE, bool SINGLE, bool SORTED>
+#ifndef D2D_STEP_ABLATE
+#define D2D_STEP_ABLATE 0       /* diagnostic build: honour StepArgs::ablate (tools/ab_step.py ablate) */
+#endif
+#define ABL(bit) (D2D_STEP_ABLATE && (a.ablate & (bit)))
+
+template <int MODE, bool SINGLE, bool FULL>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int N = a.N, R = a.R, D = a.D, W = a.mask_words, TPE = a.tpe;
     const int tid = threadIdx.x;
     // env slot in this workgroup (wave-uniform: TPE % 64 == 0); tid / TPE by multiply-shift, exact for tid < 1024
-    const int e = (int)(((unsigned)tid * a.tpe_magic) >> 20), lt = tid - e * TPE;
-    const int b = blockIdx.x * a.epw + e;
-    const bool active = e < a.epw && b < a.B;
+    const int e = FULL ? 0 : (int)(((unsigned)tid * a.tpe_magic) >> 20);
+    const int lt = FULL ? tid : tid - e * TPE;
+    const int b = FULL ? (int)blockIdx.x : (int)blockIdx.x * a.epw + e;
+    const bool active = FULL || (e < a.epw && b < a.B);
     // element offsets fit 32 bits (the host refuses B * N * 6 >= 2^31): one VGPR offset + SGPR base per access
     const unsigned row = (unsigned)b * (unsigned)N;
     const unsigned act_row = (unsigned)b * (unsigned)a.act_stride;
-    const size_t env_lds = lds_env_bytes(N, R, W, a.fuse_obs);
-    Smem s = carve(smem_raw + (size_t)(e < a.epw ? e : 0) * env_lds, N, R, W, a.fuse_obs);
+    Smem s = carve(smem_raw + (FULL ? 0u : (unsigned)(e < a.epw ? e : 0) * a.lds_env), N, R, W, a.off_mask);
 
-    // ---- prologue: issue this thread's link's loads BEFORE any LDS work or barrier, so their latency overlaps pass 0
+    // ---- prologue: issue this thread's link's loads BEFORE any LDS work or barrier, so their latency overlaps pass 0.
     // Inactive lanes (lt >= N, spare env slots) load a clamped duplicate instead of branching around the loads: a
     // join after conditional loads makes the compiler wait for all of them right here.
-    const unsigned b_ld = (a.ablate & 128) ? 0u : (unsigned)(active ? b : a.B - 1);   // 128: every env re-reads env 0 (L2)
-    const LinkRaw first = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, lt < N ? lt : N - 1);
+    const unsigned b_ld = ABL(128) ? 0u : (unsigned)(active ? b : a.B - 1);
+    const LinkRaw first = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || lt < N ? lt : N - 1);
 
     // ---- pass 0: clear masks and flags
-    const int abl = a.ablate;                 // diagnostic only (tools/ablate_step.py): bits skip parts of the kernel
-    const bool want_masks = W > 0 && !(abl & 4);
+    const bool want_masks = W > 0 && !ABL(4);
     if (active) {
         if (want_masks)
-            for (int k = lt; k < R * W + W + (R + 1) / 2; k += TPE) s.mask[k] = 0ull;      // masks + per-RB words
+            for (int k = lt; k < R * W + W + R; k += TPE) s.mask[k] = 0u;      // masks + sidelink words + summaries
         if (lt < 4) s.flags[lt] = 0;
         if (lt < 16) s.red[lt] = 0.0f;
     }
-    if (!(abl & 64)) __syncthreads();
+    if (!ABL(64)) __syncthreads();
 
     // ---- pass 1: decode + stage the transmitter side of every link
     float4 me0 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -301,70 +304,25 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         decode_link(a, in, act_row, rb, p);
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(p) * in.rb_.x, __int_as_float(rb));
-        if (!SORTED) s.link[i] = tuple;
+        s.link[i] = tuple;
         if (!SINGLE) s.rx[i] = make_float2(in.pos.z, in.pos.w);
         s.aux[i] = in.ra.x & 0x0FFFFFFF;                                 // tx_dev | link_type << 24
         if (i == lt) me0 = tuple;                                        // own link stays in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
-        if (a.rb_out && !(abl & 32)) { a.rb_out[row + (unsigned)i] = rb; a.pwr_out[row + (unsigned)i] = p; }
-        if (want_masks && !(abl & 2)) {
-            const u64 bit = 1ull << (i & 63);
+        if (a.rb_out && !ABL(32)) { a.rb_out[row + (unsigned)i] = rb; a.pwr_out[row + (unsigned)i] = p; }
+        if (want_masks && !ABL(2)) {
+            const unsigned bit = 1u << (i & 31);
             if ((unsigned)rb < (unsigned)R) {
-                atomicOr(&s.mask[(size_t)(i >> 6) * R + rb], bit);
-                if (SORTED) atomicAdd(&s.rbinfo[rb], 1u);
-                else atomicOr(&s.rbinfo[rb], 1u << (i >> 6));
+                atomicOr(&s.mask[(unsigned)(i >> 5) * (unsigned)R + (unsigned)rb], bit);
+                atomicOr(&s.summ[rb], 1u << (i >> 5));
             }
             else atomicOr(&s.flags[0], FLAG_RB_OOR);
-            if (type == LINK_SIDELINK) atomicOr(&s.mask[(size_t)R * W + (i >> 6)], bit);
+            if (type == LINK_SIDELINK) atomicOr(&s.side[i >> 5], bit);
         }
     }
-    if (!(abl & 64)) __syncthreads();
+    if (!ABL(64)) __syncthreads();
     const bool use_masks = want_masks && active && !(s.flags[0] & FLAG_RB_OOR);
-    const bool skip_walk = (abl & 7) != 0;
-
-    // ---- pass 1b (STEP_RB_SORTED): stable counting sort of the transmitter tuples by RB.
-    //   rank of link i inside its bucket = number of lower-indexed members = popcount of the mask bits below i;
-    //   bucket starts = exclusive scan of the member counts (one wave per env, K consecutive RBs per lane).
-    // Ascending link order inside a bucket is what keeps the interference sum bit-identical to the other variants.
-    int my_rank = 0;
-    if (SORTED) {
-        if (use_masks && lt < N) {
-            const int rb = __float_as_int(me0.w);
-            const int wi = lt >> 6;
-            for (int w = 0; w < wi; ++w) my_rank += __popcll(s.mask[(size_t)w * R + rb]);
-            my_rank += __popcll(s.mask[(size_t)wi * R + rb] & ((1ull << (lt & 63)) - 1ull));
-        }
-        if (use_masks && lt < 64) {
-            const int K = (R + 63) >> 6;
-            const int r0 = lt * K;
-            unsigned local = 0;
-            for (int k = 0; k < K; ++k) local += (r0 + k < R) ? s.rbinfo[r0 + k] : 0u;
-            unsigned incl = local;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned t = __shfl_up(incl, o);
-                if (lt >= o) incl += t;
-            }
-            unsigned start = incl - local;
-            for (int k = 0; k < K; ++k)
-                if (r0 + k < R) {
-                    const unsigned c = s.rbinfo[r0 + k];
-                    s.rbinfo[r0 + k] = start | (c << 16);
-                    start += c;
-                }
-        }
-        __syncthreads();
-        if (active && lt < N) {
-            if (use_masks) {
-                const unsigned se = s.rbinfo[__float_as_int(me0.w)];
-                s.link[(se & 0xFFFFu) + my_rank] =
-                    make_float4(me0.x, me0.y, me0.z, __int_as_float(lt | (((first.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK) << 16)));
-            } else {
-                s.link[lt] = me0;                                        // all-pairs fallback: by link index, .w = rb
-            }
-        }
-        __syncthreads();
-    }
+    const bool skip_walk = ABL(7);
 
     const float* gtab = MODE == PL_TABLE ? a.gain_table + (size_t)b * a.table_env_stride : nullptr;
     const unsigned genv = (unsigned)(a.env_offset + (unsigned long long)b);   // global env index (RNG counter)
@@ -383,49 +341,69 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float rx_pl = in.rb_.y, rx_lin = in.rb_.z, noise = in.rb_.w;
         const float sens = in.rc.x, bw_mhz = in.rc.y;
         float acc = 0.0f;
-        float dmin = 3.0e38f;                                            // smallest squared distance met: 0 <=> 'math domain error'
-
+        int dmin = 0x7F000000;                                           // bits of the smallest squared distance met (d2 >= 0:
+                                                                         // integer order == float order); 0 <=> 'math domain error'
         if (skip_walk) {
-        } else if (SORTED && use_masks) {
-            const unsigned se = s.rbinfo[rb];
-            const int st = (int)(se & 0xFFFFu), cnt = (int)(se >> 16);       // cnt >= 1: this link itself
-            for (int k0 = 0; k0 < cnt; k0 += 4) {
-                float4 o[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) o[u] = s.link[st + min(k0 + u, cnt - 1)];   // 4 independent reads in flight
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + u;
-                    const bool use = (k < cnt) & (k != my_rank);                    // .difference({action}), simulator.py:95
-                    const int j = __float_as_int(o[u].w) & 0xFFFF;
-                    const float dx = o[u].x - rx.x, dy = o[u].y - rx.y;
-                    const float d2 = fmaf(dx, dx, dy * dy);
-                    float g;
-                    if (MODE == PL_TABLE) g = use ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
-                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = fminf(dmin, use ? d2 : dmin); }
-                    if (MODE == PL_SHADOW && use && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
-                    acc = use ? fmaf(o[u].z, g, acc) : acc;                         // simulator.py:97-101, linear mW
-                }
-            }
         } else if (use_masks) {
-            const u64* m = s.mask + rb;                                   // word w of this RB: m[w * R]
-            unsigned live = s.rbinfo[rb];                                 // non-empty words of this RB, ascending
-            while (live) {
-                const int w = __builtin_ctz(live);
-                live &= live - 1;
-                u64 word = m[(size_t)w * R];
-                if (w == (i >> 6)) word &= ~(1ull << (i & 63));          // .difference({action}), simulator.py:95
-                while (word) {
-                    const int j = (w << 6) + __builtin_ctzll(word);
-                    word &= word - 1;
-                    const float4 o = s.link[j];
-                    const float dx = o.x - rx.x, dy = o.y - rx.y;
-                    const float d2 = fmaf(dx, dx, dy * dy);
-                    float g;
-                    if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
-                    else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = fminf(dmin, d2); }
-                    if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
-                    acc = fmaf(o.z, g, acc);                             // simulator.py:97-101, linear mW
+            unsigned live = s.summ[rb];                                  // non-empty words of this RB, ascending
+            const int iw = i >> 5;
+            const unsigned self = 1u << (i & 31);
+            const unsigned* mrow = s.mask + rb;                          // word w of this RB: mrow[w * R]
+            if (a.walk == 1) {
+                // Flattened walk: a lane either fetches its next non-empty word or consumes one member; one loop
+                unsigned bits = 0u;
+                int jbase = 0;
+                while (true) {
+                    if (bits == 0u) {
+                        if (live == 0u) break;
+                        const int w = __builtin_ctz(live);
+                        live &= live - 1u;
+                        bits = mrow[(unsigned)w * (unsigned)R];
+                        if (w == iw) bits &= ~self;                      // .difference({action}), simulator.py:95
+                        jbase = w << 5;
+                    }
+                    if (bits != 0u) {
+                        const int j = jbase + __builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const float4 o = s.link[j];
+                        const float dx = o.x - rx.x, dy = o.y - rx.y;
+                        const float d2 = fmaf(dx, dx, dy * dy);
+                        float g;
+                        if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
+                        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = min(dmin, __float_as_int(d2)); }
+                        if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
+                        acc = fmaf(o.z, g, acc);                         // simulator.py:97-101, linear mW
+                    }
+                }
+            } else {
+                // Nested walk: non-empty words (summary bits) outside, members of the word inside.  The NEXT word is
+                // requested before the members of the current one are consumed, so its LDS round trip overlaps theirs.
+                if (live) {
+                    int w = __builtin_ctz(live);
+                    live &= live - 1u;
+                    unsigned bits = mrow[(unsigned)w * (unsigned)R];
+                    while (true) {
+                        const bool more = live != 0u;
+                        const int wn = more ? __builtin_ctz(live) : w;
+                        const unsigned bits_n = mrow[(unsigned)wn * (unsigned)R];      // prefetch (a re-read when !more)
+                        if (w == iw) bits &= ~self;                      // .difference({action}), simulator.py:95
+                        while (bits) {
+                            const int j = (w << 5) + __builtin_ctz(bits);
+                            bits &= bits - 1u;
+                            const float4 o = s.link[j];
+                            const float dx = o.x - rx.x, dy = o.y - rx.y;
+                            const float d2 = fmaf(dx, dx, dy * dy);
+                            float g;
+                            if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
+                            else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = min(dmin, __float_as_int(d2)); }
+                            if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
+                            acc = fmaf(o.z, g, acc);                     // simulator.py:97-101, linear mW
+                        }
+                        if (!more) break;
+                        live &= live - 1u;
+                        w = wn;
+                        bits = bits_n;
+                    }
                 }
             }
         } else {
@@ -437,7 +415,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
-                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = fminf(dmin, same ? d2 : dmin); }
+                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
                 if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                 acc = same ? fmaf(o.z, g, acc) : acc;
             }
@@ -448,7 +426,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
-        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); dmin = fminf(dmin, d2); }
+        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); dmin = min(dmin, __float_as_int(d2)); }
         float sig = me.z * g * rx_pl * rx_lin;                           // mW at the receiver, with rx gains
         float sig_snr = sig;
         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
@@ -469,13 +447,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float rate = ok ? sh : 0.0f;
         const float cap = ok ? bw_mhz * sh : 0.0f;                       // simulator.py:150-151
 
-        if (!(abl & 8)) {
+        if (!ABL(8)) {
             a.sinr_db[row + (unsigned)i] = sinr_db;
             a.snr_db[row + (unsigned)i] = snr_db;
             a.rate[row + (unsigned)i] = rate;
             a.cap[row + (unsigned)i] = cap;
         }
-        if (a.write_table && !(abl & 16)) {                              // obs_fn.py:57-60
+        if (a.write_table && !ABL(16)) {                                 // obs_fn.py:57-60
             float2* t = reinterpret_cast<float2*>(a.table) + (row + (unsigned)i) * 3u;
             t[0] = make_float2(me.x, me.y);
             t[1] = rx;
@@ -497,7 +475,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 bool hit = false;
                 if (use_masks) {
                     for (int w = 0; w < W; ++w)
-                        hit |= (s.mask[(size_t)w * R + rb] & s.mask[(size_t)R * W + w]) != 0ull;
+                        hit |= (s.mask[(unsigned)w * (unsigned)R + (unsigned)rb] & s.side[w]) != 0u;
                 } else {
                     for (int k = 0; k < N; ++k)
                         hit |= (k != i) & ((s.aux[k] >> 24) == LINK_SIDELINK) & (__float_as_int(s.link[k].w) == rb);
@@ -506,12 +484,38 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             }
         }
         cap_part += cap;
-        if (dmin == 0.0f) my_flags |= FLAG_ZERO_DISTANCE;
+        if (dmin == 0) my_flags |= FLAG_ZERO_DISTANCE;
         if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
     }
     if (my_flags) atomicOr(&s.flags[0], my_flags);
 
     // ---- pass 3: reward
+    if (FULL && a.reward_fn != 3) {
+        // No barrier: every wave publishes its part with LDS atomics, takes a ticket, and the wave that draws the last
+        // ticket (all other waves' atomics precede their ticket in LDS order) finishes the env.  The capacity sum is
+        // accumulated in 2^-32 Mbps fixed point, so the 64-bit integer total does not depend on arrival order.
+        const int lane = tid & 63;
+        if (a.reward_fn == 2) a.reward[row + (unsigned)tid] = s.sinr[tid] >= a.reward_param ? s.sh[tid] : -1.0f;   // reward_fn.py:52-57
+        int ticket = 0;
+        if (a.reward_fn == 1) {
+            const float wsum = wave_sum(cap_part);
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), (unsigned long long)(wsum * 4294967296.0f));
+            if (violated) atomicOr(&s.flags[1], 1);
+        }
+        if (lane == 0) ticket = atomicAdd(&s.flags[2], 1);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket == (TPE >> 6) - 1) {
+            if (a.reward_fn == 1) {
+                // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone on a violation
+                const unsigned long long tot = *reinterpret_cast<volatile unsigned long long*>(s.red);
+                const float total = (float)tot * 2.3283064365386963e-10f;
+                const float r = *reinterpret_cast<volatile int*>(&s.flags[1]) ? -1.0f : total * a.inv_n;
+                for (int k = lane; k < N; k += 64) a.reward[row + (unsigned)k] = r;
+            }
+            if (lane == 0) a.env_flags[b] = *reinterpret_cast<volatile int*>(&s.flags[0]);
+        }
+        return;
+    }
     if (a.reward_fn == 1) {
         // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone if any link reported
         // a violation above.  One barrier: wave partial sums + the violation flag.
@@ -536,23 +540,16 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         FOR_MY_LINKS(i) {
             const int rbi = i == lt ? __float_as_int(me0.w) : __float_as_int(s.link[i].w);
             bool bad = false;
-            if (SORTED && use_masks) {
-                const unsigned se = s.rbinfo[rbi];
-                const int st = (int)(se & 0xFFFFu), cnt = (int)(se >> 16);
-                for (int k = 0; k < cnt; ++k) {
-                    const int wj = __float_as_int(s.link[st + k].w);
-                    bad |= (k != my_rank) & ((wj >> 16) != LINK_SIDELINK) & (s.sinr[wj & 0xFFFF] < a.reward_param);
-                }
-            } else if (use_masks) {
-                unsigned live = s.rbinfo[rbi];
+            if (use_masks) {
+                unsigned live = s.summ[rbi];
                 while (live) {
                     const int w = __builtin_ctz(live);
-                    live &= live - 1;
-                    u64 word = s.mask[(size_t)w * R + rbi] & ~s.mask[(size_t)R * W + w];   // non-sidelink members
-                    if (w == (i >> 6)) word &= ~(1ull << (i & 63));
+                    live &= live - 1u;
+                    unsigned word = s.mask[(unsigned)w * (unsigned)R + (unsigned)rbi] & ~s.side[w];   // non-sidelink members
+                    if (w == (i >> 5)) word &= ~(1u << (i & 31));
                     while (word) {
-                        const int j = (w << 6) + __builtin_ctzll(word);
-                        word &= word - 1;
+                        const int j = (w << 5) + __builtin_ctz(word);
+                        word &= word - 1u;
                         bad |= s.sinr[j] < a.reward_param;
                     }
                 }
@@ -573,14 +570,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // ---- pass 4 (small N only): LinearObs expansion of this workgroup's envs, obs_fn.py:43-53.  Every thread of the
     // workgroup streams 16-byte (or 8-byte, odd N) stores over the contiguous [N][6N] block of each env; tflat was
     // published by the reward pass's barrier.  Same mapping as csrc/d2d_obs.hip (bit-identical output).
-    if (a.fuse_obs) {
+    if (!FULL && a.fuse_obs) {
         const unsigned T = blockDim.x, q_per_row = a.obs_q_per_row, total = (unsigned)N * q_per_row;
         const unsigned row_floats = 6u * (unsigned)N;
         for (int el = 0; el < a.epw; ++el) {
             const int be = blockIdx.x * a.epw + el;
             if (be >= a.B) break;
-            const float* t_flat = reinterpret_cast<const float*>(
-                smem_raw + (size_t)el * env_lds + LDS_TFLAT_OFFSET(N));
+            const float* t_flat = reinterpret_cast<const float*>(smem_raw + (unsigned)el * a.lds_env + LDS_HEAD_BYTES + 40u * (unsigned)N);
             float* out = a.obs + (size_t)be * N * row_floats;
 #pragma unroll 2
             for (unsigned idx = tid; idx < total; idx += T) {
@@ -645,24 +641,24 @@ hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const i
 }
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream) {
-    const size_t lds = step_lds_bytes_per_env(a.N, a.R, a.mask_words, a.fuse_obs) * (size_t)a.epw;
+    const size_t lds = (size_t)a.lds_env * (size_t)a.epw;
     dim3 grid((unsigned)((a.B + a.epw - 1) / a.epw)), block(block_threads);
     hipError_t err = hipSuccess;
     const bool single = a.N <= a.tpe;
-    const bool sorted = a.variant == STEP_RB_SORTED && single && a.mask_words > 0;
-#define D2D_LAUNCH_1(M, S, Q)                                                                            \
+    const bool full = single && a.epw == 1 && a.N == a.tpe && block_threads == a.tpe && !a.fuse_obs;
+#define D2D_LAUNCH_1(M, S, F)                                                                            \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M, S, Q>),              \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M, S, F>),              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         if (err == hipSuccess) {                                                                         \
-            hipLaunchKernelGGL((step_kernel<M, S, Q>), grid, block, lds, stream, a);                     \
+            hipLaunchKernelGGL((step_kernel<M, S, F>), grid, block, lds, stream, a);                     \
             err = hipGetLastError();                                                                     \
         }                                                                                                \
     } while (0)
 #define D2D_LAUNCH(M)                                                                                    \
     do {                                                                                                 \
-        if (sorted) D2D_LAUNCH_1(M, true, true);                                                         \
+        if (full) D2D_LAUNCH_1(M, true, true);                                                           \
         else if (single) D2D_LAUNCH_1(M, true, false);                                                   \
         else D2D_LAUNCH_1(M, false, false);                                                              \
     } while (0)

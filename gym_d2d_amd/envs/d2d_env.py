@@ -13,7 +13,7 @@ from typing import Any, Dict, Tuple
 import numpy as np
 
 from .. import _native
-from ..actions import Action, Actions
+from ..actions import Action, Actions, make_action
 from ..id import Id
 from ..simulator import BASE_STATION_ID, NativeState, Simulator
 from ..spaces import Dict as DictSpace
@@ -47,6 +47,7 @@ class D2DEnv(Env):
         self.actions = None
         self.state = None
         self.num_steps = 0
+        self._key_cache: Dict[str, tuple] = {}     # 'tx:rx' -> (ids, tx device, rx device, link type, power levels)
         # plugin lowering: built-ins run inside the kernels, anything else is Python over the GPU results
         h = self.simulator.handle
         self._native_obs = isinstance(self.obs_fn, LinearObsFunction) and \
@@ -125,10 +126,25 @@ class D2DEnv(Env):
         return acts
 
     def _extract_actions(self, raw_actions: Dict[str, Any]) -> Actions:
+        """{'tx:rx': raw} -> Actions (d2d_env.py:73-101).  Key parsing, link typing and the device lookups are cached
+        per key string - agents' keys repeat every step."""
         acts = Actions()
+        data, cache = acts.data, self._key_cache
         for pair, raw in raw_actions.items():
-            ids = tuple(Id(part) for part in pair.split(':'))
-            acts[ids] = self._extract_action(*ids, raw)      # TypeError unless the key is exactly 'tx:rx'
+            ent = cache.get(pair)
+            if ent is None:
+                ids = tuple(Id(part) for part in pair.split(':'))
+                if len(ids) != 2:                                # the reference's _extract_action(*ids, raw) arity error
+                    raise TypeError(f"action key must be 'tx_id:rx_id', got {pair!r}")
+                link_type, kind = self.simulator.classify(ids[0])
+                devs = self.simulator.devices
+                ent = cache[pair] = (ids, devs[ids[0]], devs[ids[1]], link_type, self.num_pwr_actions[kind], kind)
+            ids, tx, rx, link_type, levels, kind = ent
+            if type(raw) is int:
+                rb, pwr = divmod(raw, levels)
+            else:
+                rb, pwr = self._decode_action(raw, kind)
+            data[ids] = make_action(tx, rx, link_type, rb, pwr)
         return acts
 
     def _extract_action(self, tx_id: Id, rx_id: Id, action: Any) -> Action:
@@ -151,7 +167,14 @@ class D2DEnv(Env):
         return int(rb), int(pwr)
 
     def _infos(self, actions: Actions, state: dict) -> Dict[str, Any]:
-        return {':'.join(ids): self._info(act, state) for ids, act in actions.items()}
+        lists = getattr(state, 'lists', None)
+        if lists is None:
+            return {':'.join(ids): self._info(act, state) for ids, act in actions.items()}
+        # same six keys as _info, read positionally from the step's result arrays (agent order == actions' order)
+        snr, sinr, rate, cap = lists['snrs_db'], lists['sinrs_db'], lists['rate_bps'], lists['capacity_mbps']
+        return {':'.join(ids): {'rb': act.rb, 'tx_pwr_dbm': act.tx_pwr_dBm, 'snr_db': snr[k], 'sinr_db': sinr[k],
+                                'rate_bps': rate[k], 'capacity_mbps': cap[k]}
+                for k, (ids, act) in enumerate(actions.items())}
 
     def _info(self, action: Action, state: dict) -> Dict[str, Any]:
         ids = (action.tx.id, action.rx.id)

@@ -62,8 +62,9 @@ class NativeState(dict):
     def __init__(self, keys: Sequence[Tuple[Id, Id]], arrays: Dict[str, np.ndarray]) -> None:
         super().__init__()
         self.arrays = arrays
+        self.lists = {name: arrays[name].tolist() for name, _ in self.FIELDS}   # Python floats, as the reference's dicts hold
         for name, _ in self.FIELDS:
-            self[name] = dict(zip(keys, arrays[name].tolist()))        # Python floats, as the reference's dicts hold
+            self[name] = dict(zip(keys, self.lists[name]))
         self.linear_obs: Optional[np.ndarray] = None
         self.obs_table: Optional[np.ndarray] = None
         self.native_reward: Optional[np.ndarray] = None
@@ -167,10 +168,11 @@ class Simulator:
 
     def set_links(self, keys: Iterable[Tuple[Id, Id]]) -> None:
         """Select which (tx_id, rx_id) pairs act, in agent order.  Cached: re-uploading only on change."""
-        keys = [(Id(t), Id(r)) for t, r in keys]
         sig = tuple(keys)
         if sig == self._link_sig:
             return
+        keys = [(Id(t), Id(r)) for t, r in sig]
+        sig = tuple(keys)
         tx = [self.devices.index_of(t) for t, _ in keys]        # KeyError for unknown ids, as devices.py:28
         rx = [self.devices.index_of(r) for _, r in keys]
         types = [self.classify(t)[0].value for t, _ in keys]
@@ -256,9 +258,9 @@ class Simulator:
         if len(actions) == 0:
             raise ZeroDivisionError('division by zero')      # what reward_fn.py:42 does with no actions
         self.set_links(actions.keys())
-        acts = list(actions.values())
-        rb = np.array([[a.rb for a in acts]], dtype=np.int32)
-        pwr = np.array([[int(a.tx_pwr_dBm) for a in acts]], dtype=np.int32)
+        acts = actions.values()
+        rb = np.fromiter((a.rb for a in acts), dtype=np.int32, count=len(actions))[None]
+        pwr = np.fromiter((a.tx_pwr_dBm for a in acts), dtype=np.int32, count=len(actions))[None]
         res = self.handle.step_host(rb, pwr)
         if int(res['env_flags'][0]) & _native.FLAG_ZERO_DISTANCE:
             raise ValueError('math domain error')            # log10(0) in path_loss.py:66

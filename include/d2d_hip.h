@@ -174,14 +174,14 @@ typedef enum d2d_tuning {
     D2D_TUNE_STEP_THREADS = 5,     /* threads per ENV in the step kernel; 0 = auto (one per link)    */
     D2D_TUNE_STEP_ENVS_PER_WG = 6, /* envs sharing one step workgroup; 0 = auto                      */
     D2D_TUNE_STEP_BLOCK = 7,       /* threads per step workgroup (>= envs * threads/env); 0 = auto   */
-    D2D_TUNE_STEP_VARIANT = 8,     /* same-RB interferer search: 0 bitmask walk, 1 RB-sorted buckets
-                                      (stable counting sort); -1 = auto.  Bit-identical results.     */
-    D2D_TUNE_STEP_FUSE_OBS = 9,    /* LinearObs expansion inside the step launch: 1 on, 0 off,
+    D2D_TUNE_STEP_FUSE_OBS = 8,    /* LinearObs expansion inside the step launch: 1 on, 0 off,
                                       -1 = auto (on for small N, where two launches are latency bound) */
-    D2D_TUNE_STEP_ABLATE = 10      /* DIAGNOSTIC, the one key that DOES change results: bit mask of kernel
-                                      parts to skip (1 interferer walk, 2 mask build, 4 mask clear, 8 result
-                                      stores, 16 table store, 32 rb/pwr stores) so the rest can be timed
-                                      (tools/ab_step.py ablate).  0 = normal operation.                */
+    D2D_TUNE_STEP_WALK = 10,       /* mask walk loop shape: 0 nested (words / members), 1 flattened; -1 = auto */
+    D2D_TUNE_STEP_ABLATE = 9,      /* DIAGNOSTIC builds only (D2D_BUILD_DIAG=1), the one key that DOES change
+                                      results: bit mask of kernel parts to skip (1 interferer walk, 2 mask
+                                      build, 4 mask clear, 8 result stores, 16 table store, 32 rb/pwr stores,
+                                      64 pass-0/1 barriers, 128 per-env loads hit L2) so the rest can be timed
+                                      (tools/ab_step.py ablate).  Release builds refuse any value but 0.    */
 } d2d_tuning;
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
 

@@ -48,35 +48,32 @@ def _snapshot(sim, native, with_obs):
                                    (9, 1, 64, 64)])
 @pytest.mark.parametrize('reward', [1, 2, 3])
 def test_interferer_search_variants_are_bit_identical(native, shape, reward):
-    """Bitmask walk, RB-sorted buckets (stable counting sort) and the masked all-pairs sweep visit interferers in the
-    same ascending link order through the same fmaf: every output must agree bit for bit (and match the oracle)."""
+    """The bitmask walk and the masked all-pairs sweep visit interferers in the same ascending link order through the
+    same fmaf: every output must agree bit for bit (and match the oracle)."""
     b, rbs, cues, dues = shape
     sim, pos, raw = _batch(native, b, rbs, cues, dues, seed=sum(shape) + reward)
     h = sim.handle
     h.set_obs_mode(native.OBS_TABLE)
     h.set_reward(reward, {1: 0.0, 2: -70.0, 3: 0.0}[reward])
     snaps = {}
-    for name, bucket, variant in (('mask_walk', True, native.STEP_MASK_WALK), ('rb_sorted', True, native.STEP_RB_SORTED),
-                                  ('all_pairs', False, native.STEP_MASK_WALK)):
+    for name, bucket in (('mask_walk', True), ('all_pairs', False)):
         h.set_bucketing(bucket)
-        h.set_tuning(native.TUNE_STEP_VARIANT, variant)
         sim.step_arrays(raw)
         snaps[name] = _snapshot(sim, native, False)
-    for name in ('rb_sorted', 'all_pairs'):
-        for buf, ref in snaps['mask_walk'].items():
-            assert np.array_equal(snaps[name][buf], ref), (name, buf)
+    for buf, ref in snaps['mask_walk'].items():
+        assert np.array_equal(snaps['all_pairs'][buf], ref), buf
     ids, cfgs, is_bs = orc.device_configs(cues, dues)
     tx, rx, ty = default_links(cues, dues)
     ref = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(cfgs, is_bs), orc.PathLossSpec(),
                         with_obs=False, chunk=8)
-    assert rel_err(snaps['rb_sorted']['BUF_SINR_DB'], ref['sinr_db']) <= TOL
-    assert rel_err(snaps['rb_sorted']['BUF_CAPACITY'], ref['capacity_mbps']) <= TOL
+    assert rel_err(snaps['mask_walk']['BUF_SINR_DB'], ref['sinr_db']) <= TOL
+    assert rel_err(snaps['mask_walk']['BUF_CAPACITY'], ref['capacity_mbps']) <= TOL
     if reward == 1:
-        assert rel_err(snaps['rb_sorted']['BUF_REWARD'][:, 0], ref['reward']) <= TOL
+        assert rel_err(snaps['mask_walk']['BUF_REWARD'][:, 0], ref['reward']) <= TOL
     elif reward == 2:
-        assert rel_err(snaps['rb_sorted']['BUF_REWARD'], orc.reward_shannon(ref['sinr_db'])) <= TOL
+        assert rel_err(snaps['mask_walk']['BUF_REWARD'], orc.reward_shannon(ref['sinr_db'])) <= TOL
     else:
-        assert rel_err(snaps['rb_sorted']['BUF_REWARD'], orc.reward_cue_sinr_shannon(ref['sinr_db'], ref['rb'], ty)) <= TOL
+        assert rel_err(snaps['mask_walk']['BUF_REWARD'], orc.reward_cue_sinr_shannon(ref['sinr_db'], ref['rb'], ty)) <= TOL
     sim.handle.close()
 
 
@@ -89,11 +86,11 @@ def test_envs_per_workgroup_and_fused_obs_are_bit_identical(native, shape):
     h = sim.handle
     h.set_obs_mode(native.OBS_LINEAR)
     ref = None
-    for variant in (native.STEP_MASK_WALK, native.STEP_RB_SORTED):
+    for bucket in (True, False):
+        h.set_bucketing(bucket)
         for epw, fuse, block in ((1, 0, 0), (1, 1, 0), (2, 1, 0), (4, 0, 0), (4, 1, 512), (3, 1, 1024), (0, -1, 0)):
             if epw * ((cues + dues + 63) // 64) * 64 > 1024:
                 continue
-            h.set_tuning(native.TUNE_STEP_VARIANT, variant)
             h.set_tuning(native.TUNE_STEP_ENVS_PER_WG, epw)
             h.set_tuning(native.TUNE_STEP_FUSE_OBS, fuse)
             h.set_tuning(native.TUNE_STEP_BLOCK, block)
@@ -107,7 +104,7 @@ def test_envs_per_workgroup_and_fused_obs_are_bit_identical(native, shape):
                 assert rel_err(snap['BUF_OBS'], want['obs']) <= TOL
                 assert (snap['BUF_OBS'] == orc.expand_obs(snap['BUF_OBS_TABLE'])).all()
             for buf, r in ref.items():
-                assert np.array_equal(snap[buf], r, equal_nan=True), (variant, epw, fuse, block, buf)
+                assert np.array_equal(snap[buf], r, equal_nan=True), (bucket, epw, fuse, block, buf)
     sim.handle.close()
 
 

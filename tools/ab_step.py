@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B sweeps of the step kernel, interleaved rounds in ONE process (HIP events around every launch):
 
-    python tools/ab_step.py stress     # 4096 x 512, compact-obs mode: mask walk vs RB-sorted vs all-pairs, per reward fn
+    python tools/ab_step.py stress     # 4096 x 512, compact-obs mode: mask walk vs all-pairs, per reward fn (the RB-sorted
+                                       # variant of round 2 lives in git history; its A/B is profiles/r2_ab_step_variants_stress.jsonl)
+    python tools/ab_step.py ablate     # diagnostic build only (D2D_BUILD_DIAG=1): parts of the kernel skipped
     python tools/ab_step.py default    # 1024 x 50, LinearObs: envs per workgroup x fused obs x block size
     python tools/ab_step.py wall       # 1024 x 50: wall-clock per step (no per-launch events), fused vs two launches
 
@@ -45,7 +47,7 @@ def stress(args):
     env.reset(seed=1)
     h = env.simulator.handle
     act = env.action_buffer()
-    variants = [(rw, name) for rw in (1, 0, 2, 3) for name in ('mask_walk', 'rb_sorted', 'all_pairs')]
+    variants = [(rw, name) for rw in (1, 0, 2, 3) for name in ('mask_walk_nested', 'mask_walk_flat', 'all_pairs')]
     times = {v: [] for v in variants}
     for rnd in range(args.rounds):
         for v in variants:
@@ -53,7 +55,7 @@ def stress(args):
                 continue
             h.set_reward(v[0], {0: 0.0, 1: 0.0, 2: -70.0, 3: 0.0}[v[0]])
             h.set_bucketing(v[1] != 'all_pairs')
-            h.set_tuning(_native.TUNE_STEP_VARIANT, _native.STEP_RB_SORTED if v[1] == 'rb_sorted' else _native.STEP_MASK_WALK)
+            h.set_tuning(_native.TUNE_STEP_WALK, 1 if v[1] == 'mask_walk_flat' else 0)
             times[v].append(timed(h, act, 10))
     bytes_per = b * (c + p) * 64.0
     for v in variants:
@@ -75,12 +77,11 @@ def ablate(args):
              16: '-table_store', 32: '-rb_pwr_stores', 56: '-all_stores', 63: 'loads + decode + math only',
              63 + 64: 'loads + decode + math only, no pass-0/1 barriers', 63 + 128: 'math only: per-env loads hit L2 (env 0)',
              63 + 192: 'math only, L2 loads, no pass-0/1 barriers', 128: 'full, but per-env loads hit L2 (env 0)'}
-    variants = [(rw, var, ab) for rw in (1, 0) for var in ((0, 1) if args.both else (0,)) for ab in names]
+    variants = [(rw, 0, ab) for rw in (1, 0) for ab in names]
     times = {v: [] for v in variants}
     for rnd in range(args.rounds):
         for v in variants:
             h.set_reward(v[0], 0.0)
-            h.set_tuning(_native.TUNE_STEP_VARIANT, v[1])
             h.set_tuning(_native.TUNE_STEP_ABLATE, v[2])
             times[v].append(timed(h, act, 10))
     h.set_tuning(_native.TUNE_STEP_ABLATE, 0)
@@ -97,7 +98,7 @@ def default(args):
     env.reset(seed=1)
     h = env.simulator.handle
     act = env.action_buffer()
-    variants = [(epw, fuse, blk, var) for var in (0, 1) for fuse in (1, 0) for epw in (1, 2, 4, 8)
+    variants = [(epw, fuse, blk, var) for var in (0,) for fuse in (1, 0) for epw in (1, 2, 4, 8)
                 for blk in ((0, 256, 512, 1024) if fuse else (0,)) if blk == 0 or blk >= epw * 64]
     times = {v: [] for v in variants}
     for rnd in range(args.rounds):
@@ -105,7 +106,6 @@ def default(args):
             h.set_tuning(_native.TUNE_STEP_ENVS_PER_WG, v[0])
             h.set_tuning(_native.TUNE_STEP_FUSE_OBS, v[1])
             h.set_tuning(_native.TUNE_STEP_BLOCK, v[2])
-            h.set_tuning(_native.TUNE_STEP_VARIANT, v[3])
             t_step = timed(h, act, 20, 0)
             t_obs = 0.0 if v[1] else timed(h, act, 20, 1)
             times[v].append((t_step, t_obs))
@@ -150,6 +150,5 @@ if __name__ == '__main__':
     ap.add_argument('what', choices=['stress', 'default', 'wall', 'ablate'])
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--out', default='')
-    ap.add_argument('--both', action='store_true', help='ablate: both interferer-search variants')
     a = ap.parse_args()
     {'stress': stress, 'default': default, 'wall': wall, 'ablate': ablate}[a.what](a)

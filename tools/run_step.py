@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run K steps of one workload and nothing else - the program rocprofv3 wraps (kernel trace / PMC passes).
 
-    python3 tools/run_step.py [--workload stress|default] [--obs table|linear] [--steps K] [--variant V] [--ablate A]
+    python3 tools/run_step.py [--workload stress|default] [--obs table|linear] [--steps K] [--ablate A (diagnostic build)]
 """
 import argparse
 import sys
@@ -18,7 +18,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--workload', default='stress')
 ap.add_argument('--obs', default='table')
 ap.add_argument('--steps', type=int, default=20)
-ap.add_argument('--variant', type=int, default=-1)
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--reward', type=int, default=1)
 a = ap.parse_args()
@@ -29,8 +28,8 @@ env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p,
 env.reset(seed=1)
 h = env.simulator.handle
 h.set_reward(a.reward, 0.0)
-h.set_tuning(_native.TUNE_STEP_VARIANT, a.variant)
-h.set_tuning(_native.TUNE_STEP_ABLATE, a.ablate)
+if a.ablate:
+    h.set_tuning(_native.TUNE_STEP_ABLATE, a.ablate)
 acts = torch.randint(0, r * 21, (8,) + tuple(env.action_buffer().shape), device=env.device, dtype=torch.int32)
 for k in range(a.steps):
     h.step(acts[k % 8].data_ptr())
