@@ -174,7 +174,7 @@ class D2DEnv(Env):
         snr, sinr, rate, cap = lists['snrs_db'], lists['sinrs_db'], lists['rate_bps'], lists['capacity_mbps']
         return {':'.join(ids): {'rb': act.rb, 'tx_pwr_dbm': act.tx_pwr_dBm, 'snr_db': snr[k], 'sinr_db': sinr[k],
                                 'rate_bps': rate[k], 'capacity_mbps': cap[k]}
-                for k, (ids, act) in enumerate(actions.items())}
+                for k, (ids, act) in enumerate(getattr(actions, 'data', actions).items())}
 
     def _info(self, action: Action, state: dict) -> Dict[str, Any]:
         ids = (action.tx.id, action.rx.id)

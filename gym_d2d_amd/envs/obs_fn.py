@@ -46,7 +46,7 @@ class LinearObsFunction(ObsFunction):
         if obs is None:
             raise RuntimeError('LinearObsFunction is evaluated by the HIP obs kernel; `state` must be the NativeState '
                                'returned by gym_d2d_amd.Simulator.step (there is no host implementation)')
-        return {':'.join(ids): obs[k] for k, ids in enumerate(actions.keys())}
+        return dict(zip(map(':'.join, getattr(actions, 'data', actions).keys()), obs))     # rows of the [N, 6N] block
 
 
 class ArrayObsFunction(ABC):

@@ -25,7 +25,7 @@ class RewardFunction(ABC):
         if got is None or getattr(state, 'native_reward_key', None) != (self.native_id, float(self.native_param)):
             raise RuntimeError(f'{type(self).__name__} is evaluated by the HIP step kernel; `state` must be the '
                                'NativeState of an env configured with this reward function')
-        return dict(zip(map(':'.join, actions.keys()), got.tolist()))
+        return dict(zip(map(':'.join, getattr(actions, 'data', actions).keys()), got.tolist()))
 
 
 class SystemCapacityRewardFunction(RewardFunction):

@@ -258,7 +258,7 @@ class Simulator:
         if len(actions) == 0:
             raise ZeroDivisionError('division by zero')      # what reward_fn.py:42 does with no actions
         self.set_links(actions.keys())
-        acts = actions.values()
+        acts = list(getattr(actions, 'data', actions).values())     # UserDict: the dict's own view, not the abc mixin
         rb = np.fromiter((a.rb for a in acts), dtype=np.int32, count=len(actions))[None]
         pwr = np.fromiter((a.tx_pwr_dBm for a in acts), dtype=np.int32, count=len(actions))[None]
         res = self.handle.step_host(rb, pwr)

@@ -56,8 +56,30 @@ int main(void) {
     CK(d2d_download(h, D2D_BUF_SINR_DB, sinr, sizeof sinr, 0));
     CK(d2d_download(h, D2D_BUF_REWARD, reward, sizeof reward, 0));
     CK(d2d_download(h, D2D_BUF_OBS, obs, sizeof obs, 0));
-    printf("{\"flags\": %u, \"sinr_db\": [%.6f, %.6f, %.6f, %.6f], \"reward\": %.6f, \"obs_1_0\": %.3f}\n", flags, sinr[0],
-           sinr[1], sinr[2], sinr[3], reward[0], obs[1 * 6 * N + 0]);
+    /* the host-caller's transport (d2d_step_host): explicit (rb, pwr) in, every result in ONE pinned block out */
+    const int32_t rb[N] = {0, 1, 0, 1}, pw[N] = {23, 10, 20, 5};
+    const void* block = NULL;
+    d2d_host_layout lay;
+    CK(d2d_step_host(h, rb, pw, &block, &lay));
+    const float* h_sinr = (const float*)((const char*)block + lay.sinr_db);
+    const float* h_obs = (const float*)((const char*)block + lay.obs);
+    int host_match = lay.total_bytes > lay.obs;
+    for (int i = 0; i < N; ++i) host_match &= h_sinr[i] == sinr[i];
+    for (int i = 0; i < N * 6 * N; ++i) host_match &= h_obs[i] == obs[i];
+    /* traffic-model links (d2d_set_fixed_actions): links 0 and 1 carry their (rb, pwr) in the link records, the action
+     * array shrinks to the two sidelinks - same step, same numbers */
+    const int32_t fixed_idx[2] = {0, 1}, fixed_rb[2] = {0, 1}, fixed_pw[2] = {23, 10};
+    CK(d2d_set_fixed_actions(h, 2, fixed_idx, fixed_rb, fixed_pw));
+    const int32_t due_actions[2] = {0 * 21 + 20, 1 * 21 + 5};
+    CK(d2d_upload(h, D2D_BUF_ACTIONS, due_actions, sizeof due_actions, 0));
+    CK(d2d_step(h, NULL));
+    float sinr2[N];
+    CK(d2d_download(h, D2D_BUF_SINR_DB, sinr2, sizeof sinr2, 0));
+    int fixed_match = 1;
+    for (int i = 0; i < N; ++i) fixed_match &= sinr2[i] == sinr[i];
+    printf("{\"flags\": %u, \"sinr_db\": [%.6f, %.6f, %.6f, %.6f], \"reward\": %.6f, \"obs_1_0\": %.3f, "
+           "\"host_match\": %d, \"fixed_match\": %d}\n", flags, sinr[0], sinr[1], sinr[2], sinr[3], reward[0],
+           obs[1 * 6 * N + 0], host_match, fixed_match);
     CK(d2d_destroy(h));
     return 0;
 }

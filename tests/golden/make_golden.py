@@ -172,6 +172,72 @@ def save_case(name, meta, devices, steps):
     print(f'wrote {out.name}: {len(steps)} steps, {len(ids)} devices, {out.stat().st_size} bytes')
 
 
+class _UniformFeeder:
+    """Stands in for the `random` module inside gym_d2d.position: random() hands out u[d, t, 0] (theta) then u[d, t, 1]
+    (radius) for the device / try the sampler is at."""
+
+    def __init__(self):
+        self.u = None; self.d = 0; self.t = 0; self.k = 0; self.max_t = 0
+
+    def start_device(self):
+        self.d += 1; self.t = 0; self.k = 0
+
+    def random(self):
+        v = float(self.u[self.d, self.t, self.k])
+        self.k += 1
+        if self.k == 2:
+            self.k = 0; self.t += 1; self.max_t = max(self.max_t, self.t)
+        return v
+
+
+def save_sampler_case(gym):
+    if len(sys.argv) > 1 and not any(tag in 'sampler_case15' for tag in sys.argv[1:]):
+        return
+    sys.path.insert(0, str(HERE.parent.parent))
+    from oracle import d2d_oracle as orc
+    import gym_d2d.position as ref_position
+    import gym_d2d.simulator as ref_simulator
+    feeder = _UniformFeeder()
+    orig = (ref_position.random, ref_simulator.get_random_position, ref_simulator.get_random_position_nearby)
+
+    def wrap(fn):
+        def inner(*a, **kw):
+            feeder.start_device()
+            return fn(*a, **kw)
+        return inner
+    out = {}
+    meta = {'case': 'sampler_case15', 'configs': []}
+    try:
+        ref_position.random = feeder
+        ref_simulator.get_random_position = wrap(orig[1])
+        ref_simulator.get_random_position_nearby = wrap(orig[2])
+        for tag, cues, dues, radius, d2d, seed, episode, first_env, envs in (
+                ('default_radii', 7, 9, 500.0, 20.0, 0x1234_5678_9ABC, 3, 1000, 48),
+                ('tight_cell', 3, 12, 30.0, 25.0, 77, 0, 0, 48)):              # d2d radius ~ cell radius: many rejections
+            d = 1 + cues + 2 * dues
+            u = orc.reset_uniforms(seed, episode, envs, d, 64, first_env=first_env)
+            pos = np.zeros((envs, d, 2))
+            env = gym.make('D2DEnv-v0', env_config={'num_cues': cues, 'num_due_pairs': dues, 'cell_radius_m': radius,
+                                                    'd2d_radius_m': d2d})
+            for e in range(envs):
+                feeder.u = u[e]; feeder.d = 0; feeder.t = 0; feeder.k = 0
+                env.simulator.reset()
+                assert feeder.d == d - 1, (feeder.d, d)
+                pos[e] = [dev.position.as_tuple() for dev in env.simulator.devices.values()]
+            tries = feeder.max_t
+            out[f'{tag}_u'] = u[:, :, :max(tries, 1) + 1]
+            out[f'{tag}_pos'] = pos
+            meta['configs'].append(dict(tag=tag, num_cues=cues, num_due_pairs=dues, cell_radius_m=radius, d2d_radius_m=d2d,
+                                        seed=seed, episode=episode, first_env=first_env, num_envs=envs, max_tries_used=tries))
+    finally:
+        ref_position.random, ref_simulator.get_random_position, ref_simulator.get_random_position_nearby = orig
+    out['meta_json'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = HERE / 'sampler_case15.npz'
+    np.savez_compressed(path, **out)
+    print(f'wrote {path.name}: {[c["tag"] for c in meta["configs"]]}, max tries {[c["max_tries_used"] for c in meta["configs"]]}, '
+          f'{path.stat().st_size} bytes')
+
+
 def seed_all(gym, k):
     random.seed(k)
     gym.spaces.seed(k)
@@ -384,6 +450,12 @@ def main():
         steps.append(rec)
     save_case('case14_traffic_model', dict(env_meta(env, ld), seed=114, case='case14_traffic_model'),
               snapshot_devices(env), steps)
+
+    # (15) the reference's own samplers - get_random_position / get_random_position_nearby (position.py:18-45) as driven
+    # by Simulator.reset (simulator.py:61-75) - fed with the counter-based Philox uniforms the device-side reset
+    # consumes (oracle.reset_uniforms) instead of Python's global Mersenne Twister: pins the oracle's sampler (and through
+    # it csrc/d2d_reset.hip) to the reference's arithmetic and call order, not just to its distributional properties.
+    save_sampler_case(gym)
 
     # known-answer values copied as DATA from the reference's own unit tests (file:line in the key)
     kat = {

@@ -51,7 +51,7 @@ def test_c_client_runs_and_matches_oracle(tmp_path):
     tx, rx, ty = np.array([1, 2, 3, 5]), np.array([0, 0, 4, 6]), np.array([1, 1, 3, 3])
     raw = np.array([[0 * 24 + 23, 1 * 24 + 10, 0 * 21 + 20, 1 * 21 + 5]])
     ref = orc.full_step(pos, tx, rx, ty, raw, cols, orc.PathLossSpec())
-    assert got['flags'] == 0
+    assert got['flags'] == 0 and got['host_match'] == 1 and got['fixed_match'] == 1
     assert np.allclose(got['sinr_db'], ref['sinr_db'][0], rtol=1e-5, atol=1e-5)
     assert abs(got['reward'] - ref['reward'][0]) <= 1e-5 * max(1.0, abs(ref['reward'][0]))
     assert abs(got['obs_1_0'] - ref['obs'][0, 1, 0]) <= 1e-3

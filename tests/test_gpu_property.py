@@ -23,24 +23,35 @@ OVERRIDABLE_BS = {'tx_antenna_gain_dBi': (10.0, 20.0), 'rx_antenna_gain_dBi': (1
 
 @st.composite
 def scenarios(draw):
-    rbs = draw(st.integers(1, 12))
-    cues = draw(st.integers(0, 9))
-    dues = draw(st.integers(0 if cues else 1, 9))
+    # about a quarter of the scenarios are "big": N > 64 links, so the membership masks span several words (and, with
+    # downlinks / overrides / the table route drawn independently, those features meet the multi-word walk too)
+    big = draw(st.integers(0, 3)) == 0
+    rbs = draw(st.integers(1, 40 if big else 12))
+    cues = draw(st.integers(35, 80) if big else st.integers(0, 9))
+    dues = draw(st.integers(35, 80) if big else st.integers(0 if cues else 1, 9))
     envs = draw(st.integers(1, 5))
     seed = draw(st.integers(0, 2 ** 31 - 1))
-    model = draw(st.sampled_from(['log2', 'ple', 'hata_urban', 'hata_suburban']))
+    model = draw(st.sampled_from(['log2', 'ple', 'hata_urban', 'hata_suburban', 'custom_table']))
     ple = draw(st.floats(2.1, 4.5)) if model == 'ple' else 2.0
     reward = draw(st.sampled_from([1, 2, 3]))
     reward_param = draw(st.sampled_from([0.0, 0.3, 5.0])) if reward == 1 else draw(st.sampled_from([-70.0, 0.0, 10.0]))
     n_over = draw(st.integers(0, 3))
     use_downlinks = draw(st.booleans()) and cues > 0
     explicit = draw(st.booleans())
-    return dict(rbs=rbs, cues=cues, dues=dues, envs=envs, seed=seed, model=model, ple=ple, reward=reward,
+    return dict(big=big, rbs=rbs, cues=cues, dues=dues, envs=envs, seed=seed, model=model, ple=ple, reward=reward,
                 reward_param=reward_param, n_over=n_over, use_downlinks=use_downlinks, explicit=explicit)
 
 
 def _path_loss(model, ple):
-    from gym_d2d_amd.path_loss import AreaType, CostHataPathLoss, LogDistancePathLoss
+    from gym_d2d_amd.path_loss import AreaType, CostHataPathLoss, LogDistancePathLoss, PathLoss
+    if model == 'custom_table':
+        import math
+
+        class UserPathLoss(PathLoss):            # an arbitrary Python plugin (examples/custom_path_loss.py style): host-
+            def __call__(self, tx, rx):          # evaluated per episode into a [B, D, D] table, kernel mode PL_TABLE
+                d = tx.position.distance(rx.position)
+                return 25.0 * math.log10(d) + 30.0 - tx.tx_antenna_gain_dBi - rx.rx_antenna_gain_dBi
+        return UserPathLoss, None                # oracle spec needs the positions: built by the test
     if model == 'log2':
         return LogDistancePathLoss, orc.PathLossSpec('log_distance', 2.1, ple=2.0)
     if model == 'ple':
@@ -56,7 +67,7 @@ def _path_loss(model, ple):
     return Hata, orc.PathLossSpec('cost_hata', 2.1, area='urban' if model == 'hata_urban' else 'suburban')
 
 
-@settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=240, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(scenarios())
 def test_random_scenarios_match_oracle(tmp_path_factory, sc):
     import json
@@ -88,6 +99,12 @@ def test_random_scenarios_match_oracle(tmp_path_factory, sc):
     cols = orc.device_columns(cfgs, is_bs)
     pos = random_layout(rng, envs, cues, dues)
     sim.set_positions(pos)
+    if spec is None:
+        p64 = pos.astype(np.float64)
+        dist = np.hypot(p64[:, :, None, 0] - p64[:, None, :, 0], p64[:, :, None, 1] - p64[:, None, :, 1])
+        with np.errstate(divide='ignore'):
+            spec = orc.PathLossSpec('table', 2.1, table_db=25.0 * np.log10(dist) + 30.0 - cols.tx_gain_dbi[None, :, None]
+                                    - cols.rx_gain_dbi[None, None, :])
     # ---- an arbitrary ordered subset of links; downlinks and uplinks never share an RB (zero distance at the BS)
     keys = []
     for c in range(cues):
@@ -125,6 +142,7 @@ def test_random_scenarios_match_oracle(tmp_path_factory, sc):
         sim.step_arrays((rb * p_levels[None, :] + pwr).astype(np.int32))
     assert sim.check_flags() & _native.FLAG_ZERO_DISTANCE == 0
     ref = orc.step(pos.astype(np.float64), sim.link_tx, sim.link_rx, rb, pwr, cols, spec)
+    TOL = 2e-5 if sc['model'] == 'custom_table' else 1e-5     # the table itself is float32: one more rounding
     for f, buf in (('sinr_db', _native.BUF_SINR_DB), ('snr_db', _native.BUF_SNR_DB), ('rate_bps', _native.BUF_RATE_BPS),
                    ('capacity_mbps', _native.BUF_CAPACITY)):
         assert rel_err(sim.fetch(buf), ref[f]) <= TOL, (sc, f)

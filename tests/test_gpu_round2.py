@@ -357,3 +357,25 @@ def test_positions_written_into_a_bound_buffer_need_positions_changed(native):
     # inverse-square law: uplink SNRs rise by exactly 20 log10(2) dB
     assert torch.allclose(info['snr_db'][:, :3] - before[:, :3], torch.full((8, 3), 6.0206, device=env.device), atol=1e-3)
     env.close()
+
+
+def test_device_reset_against_the_reference_samplers(native):
+    """csrc/d2d_reset.hip against positions the REFERENCE's samplers produced from the same Philox uniforms (golden
+    sampler_case15): fp32 sincos / sqrt vs the reference's fp64, so 1e-6 of the cell radius; a rejection decision may
+    differ only for a candidate within rounding of the cell edge."""
+    import json
+    from golden_util import GOLDEN_DIR
+    from gym_d2d_amd.simulator import Simulator
+    z = np.load(GOLDEN_DIR / 'sampler_case15.npz')
+    for c in json.loads(bytes(z['meta_json']).decode())['configs']:
+        ref = z[c['tag'] + '_pos']
+        sim = Simulator(dict(num_cues=c['num_cues'], num_due_pairs=c['num_due_pairs'], num_envs=c['num_envs'],
+                             cell_radius_m=c['cell_radius_m'], d2d_radius_m=c['d2d_radius_m']))
+        sim.handle.set_env_offset(c['first_env'])
+        sim.reset_device(seed=c['seed'], episode=c['episode'])
+        got = sim.positions().astype(np.float64)
+        close = np.abs(got - ref).max(axis=2) <= c['cell_radius_m'] * 2e-6
+        assert close.mean() > 0.995, (c['tag'], close.mean())
+        # the few misses must be rejection decisions at the cell edge: the kernel's own position is still legal
+        assert (np.hypot(got[..., 0], got[..., 1]) <= c['cell_radius_m'] * (1 + 1e-6)).all()
+        sim.handle.close()

@@ -209,3 +209,26 @@ def test_sampler_properties():
     tx = pos[:, 6::2]; rx = pos[:, 7::2]
     assert (np.hypot(*(tx - rx).transpose(2, 0, 1)) <= 20.0 + 1e-9).all()
     assert (pos[:, 0] == 0).all()
+
+
+def test_oracle_sampler_matches_the_reference_samplers_on_the_same_uniforms():
+    """Golden sampler_case15: the reference's get_random_position / get_random_position_nearby, as driven by
+    Simulator.reset (position.py:18-45, simulator.py:61-75), fed with the Philox uniforms of the device-side reset.  The
+    oracle's sampler must land on the same positions (same arithmetic, same consumption order, same rejection
+    decisions), and reset_uniforms must regenerate exactly the stream that was fed."""
+    import json
+    from golden_util import GOLDEN_DIR
+    z = np.load(GOLDEN_DIR / 'sampler_case15.npz')
+    meta = json.loads(bytes(z['meta_json']).decode())
+    assert [c['tag'] for c in meta['configs']] == ['default_radii', 'tight_cell']
+    for c in meta['configs']:
+        u, ref = z[c['tag'] + '_u'], z[c['tag'] + '_pos']
+        d = 1 + c['num_cues'] + 2 * c['num_due_pairs']
+        again = orc.reset_uniforms(c['seed'], c['episode'], c['num_envs'], d, u.shape[2], first_env=c['first_env'])
+        assert np.array_equal(again, u)
+        assert u[..., 1].min() > 0.0 and u.max() < 1.0            # radius draws on the open interval: never distance 0
+        pos, used = orc.sample_positions_from_uniforms(u, c['num_cues'], c['num_due_pairs'], c['cell_radius_m'],
+                                                       c['d2d_radius_m'])
+        assert np.abs(pos - ref).max() <= 1e-12 * c['cell_radius_m'], c['tag']
+        assert used.max() == c['max_tries_used'], c['tag']        # the rejection loop stopped at the same try everywhere
+    assert meta['configs'][1]['max_tries_used'] >= 5               # the tight cell really exercises rejection
