@@ -1,47 +1,79 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output under gpurun_out/ into the small summaries kept in profiles/.
+"""Condense the rocprofv3 output of tools/profile_bench.sh into the small summaries kept in profiles/:
 
-    python tools/summarize_profiles.py <tag> <kernel_stats.csv> <pmc_write counter_collection.csv> <pmc_fetch ...csv>
+    python tools/summarize_profiles.py <tag> <workload> <obs> <raw dir>
+
+  profiles/<tag>_kernel_stats_<workload>_<obs>.csv   kernel-trace --stats table (names shortened)
+  profiles/<tag>_pmc_<workload>_<obs>.json           per-kernel HBM bytes per launch (WRITE_SIZE + 2 * FETCH_SIZE, separate
+                                                     passes) and the SQ counters per wave, stamped with the digest of the
+                                                     kernel sources they were collected on (bench.py only quotes `traffic`
+                                                     from a summary whose digest matches the running library)
 """
 import collections
 import csv
+import glob
 import json
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def counters(raw, sub):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f'{raw}/{sub}/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'd2d::' in r['Kernel_Name']:
+                acc[r['Kernel_Name'][:70]][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
 
 
 def main():
-    tag, stats, pmc_w, pmc_f = sys.argv[1:5]
-    rows = list(csv.reader(open(stats)))
-    out = ROOT / 'profiles' / f'{tag}_kernel_stats_bench_stress_steps100.csv'
-    with open(out, 'w', newline='') as f:
-        w = csv.writer(f)
-        for r in rows:
-            r[0] = r[0][:90]                       # torch's templated kernel names run to kilobytes
-            w.writerow(r)
+    tag, wl, obs, raw = sys.argv[1:5]
+    from gym_d2d_amd.build import source_digest
+    stats = glob.glob(f'{raw}/kt/**/*kernel_stats.csv', recursive=True)
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        out = ROOT / 'profiles' / f'{tag}_kernel_stats_{wl}_{obs}.csv'
+        with open(out, 'w', newline='') as f:
+            w = csv.writer(f)
+            for r in rows:
+                r[0] = r[0][:90]                       # torch's templated kernel names run to kilobytes
+                w.writerow(r)
+        print(out.read_text()[:700])
     kernels = {}
-    for name, path in (('WRITE_SIZE', pmc_w), ('FETCH_SIZE', pmc_f)):
-        acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(path)):
-            if r['Counter_Name'] == name and 'd2d::' in r['Kernel_Name']:
-                acc[r['Kernel_Name']].append(float(r['Counter_Value']))
-        for k, v in acc.items():
-            kernels.setdefault(k, {})[name + '_KiB_mean_per_launch'] = sum(v) / len(v)
-            kernels[k][name + '_launches'] = len(v)
+    for sub, name in (('pmc_write', 'WRITE_SIZE'), ('pmc_fetch', 'FETCH_SIZE')):
+        for k, d in counters(raw, sub).items():
+            v = d.get(name, [])
+            if v:
+                kernels.setdefault(k, {})[name + '_KiB_mean_per_launch'] = sum(v) / len(v)
+                kernels[k][name + '_launches'] = len(v)
     for d in kernels.values():
         w_b = d.get('WRITE_SIZE_KiB_mean_per_launch', 0.0) * 1024
         f_b = d.get('FETCH_SIZE_KiB_mean_per_launch', 0.0) * 1024
         # gfx950: FETCH_SIZE reports half the bytes of a coalesced stream (MI355X_MICROARCH.md, HBM) -> doubled
         d['hbm_bytes_per_launch'] = w_b + 2 * f_b
-    rec = {'command': 'rocprofv3 --pmc <WRITE_SIZE|FETCH_SIZE> --output-format csv -- python3 bench.py --steps 5 --warmup 1 '
-                      '--no-cpu-baseline   (one counter per pass)',
-           'workload': 'stress: 4096 envs x 512 links, obs linear', 'kernels': kernels}
-    (ROOT / 'profiles' / f'{tag}_pmc_hbm_traffic.json').write_text(json.dumps(rec, indent=1))
-    print(out.read_text()[:600])
+    for sub in ('pmc_sq1', 'pmc_sq2'):
+        for k, d in counters(raw, sub).items():
+            sq = kernels.setdefault(k, {}).setdefault('sq_counters_mean_per_launch', {})
+            for c, v in d.items():
+                sq[c] = sum(v) / len(v)
+    for d in kernels.values():
+        sq = d.get('sq_counters_mean_per_launch')
+        if sq and sq.get('SQ_WAVES'):
+            d['sq_per_wave'] = {c: round(v / sq['SQ_WAVES'], 2) for c, v in sq.items() if c != 'SQ_WAVES'}
+            if sq.get('SQ_LDS_IDX_ACTIVE'):
+                d['lds_bank_conflict_ratio'] = round(sq.get('SQ_LDS_BANK_CONFLICT', 0.0) / sq['SQ_LDS_IDX_ACTIVE'], 3)
+            if sq.get('SQ_WAVE_CYCLES'):
+                d['wait_any_fraction_of_wave_cycles'] = round(sq.get('SQ_WAIT_ANY', 0.0) / sq['SQ_WAVE_CYCLES'], 3)
+    rec = {'command': 'tools/profile_bench.sh: rocprofv3 --pmc <one counter set per pass> --output-format csv -- python3 bench.py '
+                      f'--workload {wl} --obs {obs} --no-cpu-baseline --steps 5 --warmup 1',
+           'workload_key': f'{wl}/{obs}', 'source_digest': source_digest(), 'kernels': kernels}
+    out = ROOT / 'profiles' / f'{tag}_pmc_{wl}_{obs}.json'
+    out.write_text(json.dumps(rec, indent=1))
     for k, d in kernels.items():
-        print(k[:60], {a: round(b) for a, b in d.items()})
+        print(k[:60], {a: (round(b) if isinstance(b, float) else b) for a, b in d.items() if not isinstance(b, dict)})
 
 
 if __name__ == '__main__':
