@@ -279,6 +279,10 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     const unsigned row = (unsigned)b * (unsigned)N;
     const unsigned act_row = (unsigned)b * (unsigned)a.act_stride;
     Smem s = carve(smem_raw + (FULL ? 0u : (unsigned)(e < a.epw ? e : 0) * a.lds_env), N, R, W, a.off_mask);
+    if (ABL(1024)) {                      // diagnostic: workgroup launch only
+        if (tid == 4095) a.env_flags[b] = 1;
+        return;
+    }
 
     // ---- prologue: issue this thread's link's loads BEFORE any LDS work or barrier, so their latency overlaps pass 0.
     // Inactive lanes (lt >= N, spare env slots) load a clamped duplicate instead of branching around the loads: a
@@ -295,6 +299,10 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (lt < 16) s.red[lt] = 0.0f;
     }
     if (!ABL(64)) __syncthreads();
+    if (ABL(256)) {                       // diagnostic: launch + prologue loads + pass 0 only
+        if (first.act0 == 0x7fffffff && first.pos.x == 1.2345f && first.rb_.x == first.rc.x && first.ra.y == 77) a.env_flags[b] = 1;
+        return;
+    }
 
     // ---- pass 1: decode + stage the transmitter side of every link
     float4 me0 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -323,6 +331,10 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     if (!ABL(64)) __syncthreads();
     const bool use_masks = want_masks && active && !(s.flags[0] & FLAG_RB_OOR);
     const bool skip_walk = ABL(7);
+    if (ABL(512)) {                       // diagnostic: everything up to the end of pass 1
+        if (me0.z == 1.2345f) a.env_flags[b] = 1;
+        return;
+    }
 
     const float* gtab = MODE == PL_TABLE ? a.gain_table + (size_t)b * a.table_env_stride : nullptr;
     const unsigned genv = (unsigned)(a.env_offset + (unsigned long long)b);   // global env index (RNG counter)

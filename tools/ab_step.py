@@ -76,7 +76,10 @@ def ablate(args):
     names = {0: 'full', 1: '-walk', 3: '-walk -mask_build', 7: '-walk -mask_build -mask_clear', 8: '-result_stores',
              16: '-table_store', 32: '-rb_pwr_stores', 56: '-all_stores', 63: 'loads + decode + math only',
              63 + 64: 'loads + decode + math only, no pass-0/1 barriers', 63 + 128: 'math only: per-env loads hit L2 (env 0)',
-             63 + 192: 'math only, L2 loads, no pass-0/1 barriers', 128: 'full, but per-env loads hit L2 (env 0)'}
+             63 + 192: 'math only, L2 loads, no pass-0/1 barriers', 128: 'full, but per-env loads hit L2 (env 0)',
+             256: 'launch + prologue loads + pass 0 only', 256 + 4: 'launch + prologue loads only (no mask clear)',
+             256 + 4 + 128: 'launch + L2 loads only', 256 + 4 + 64: 'launch + prologue loads, no barrier',
+             512: 'through pass 1 (decode, staging, mask build)', 1024: 'workgroup launch only (exit at once)'}
     variants = [(rw, 0, ab) for rw in (1, 0) for ab in names]
     times = {v: [] for v in variants}
     for rnd in range(args.rounds):
