@@ -70,6 +70,7 @@ struct d2d_handle {
     Buffer buf[D2D_BUF_COUNT];
     // device-side tables
     float4* rec = nullptr;          // per-link records: 3 rows of Nmax x 16 B (d2d_internal.h), see refresh_tables
+    int* act_cols = nullptr;        // [Nmax] action column per link (arbitrary fixed sets)
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
     bool lpos_dirty = true;
     float* gain_table = nullptr;
@@ -90,6 +91,8 @@ struct d2d_handle {
     int bucketing = 1;
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
     int tune_obs_grid = 0;
+    int num_cus = 0;
+    int tune_step_prefetch = -1;                     // action prefetch distance in envs: -1 auto, 0 off
     int tune_step_epw = 0, tune_step_block = 0, tune_step_fuse = -1, tune_step_ablate = 0, tune_step_walk = -1;
     // d2d_step_host: packed device block + pinned host mirrors
     void* host_out_dev = nullptr; size_t host_out_bytes = 0;
@@ -190,6 +193,13 @@ int refresh_tables(d2d_handle* h) {
         rc[4 * i + 1] = cols[5 * D + t];    // bw_mhz
         rc[4 * i + 2] = cols[6 * D + t];    // exponent
     }
+    std::vector<int32_t> cols_host((size_t)S, 0);
+    for (int i = 0; i < N; ++i) {
+        uint32_t packed;
+        std::memcpy(&packed, &rc[4 * i + 3], 4);
+        cols_host[i] = (int32_t)(packed >> 16);
+    }
+    HIP_TRY(hipMemcpyAsync(h->act_cols, cols_host.data(), cols_host.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // rec is a stack-lifetime host buffer
     h->col_mode = prefix ? 0 : 1;
@@ -339,6 +349,16 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     if (block < epw * tpe) block = epw * tpe;
     if (block > 1024) return fail(D2D_ERR_INVALID, "step workgroup exceeds 1024 threads");
     s.tpe = tpe; s.epw = epw; s.mask_words = W; s.fuse_obs = fuse;
+    {
+        // action prefetch distance = the envs resident on the chip at once (LDS: 160 KB / CU, threads: 2048 / CU), as a
+        // multiple of 8 workgroups so that the prefetching and the consuming workgroup share an XCD (and its L2)
+        int per_cu = (int)((160 * 1024) / ((size_t)epw * env_lds ? (size_t)epw * env_lds : 1));
+        if (per_cu > 2048 / block) per_cu = 2048 / block;
+        if (per_cu < 1) per_cu = 1;
+        int dist = h->tune_step_prefetch >= 0 ? h->tune_step_prefetch : per_cu * h->num_cus * epw;
+        dist -= dist % (8 * epw);
+        s.prefetch_envs = dist;
+    }
     s.tpe_magic = ((1u << 20) + (unsigned)tpe - 1) / (unsigned)tpe;
     if (fuse) {
         s.obs_q_per_row = (unsigned)(6 * N / fuse);
@@ -394,6 +414,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.rec_b = h->rec + S;
     s.rec_c = h->rec + 2 * (size_t)S;
     s.lpos = h->lpos;
+    s.act_cols = h->act_cols;
     s.gain_table = h->gain_table;
     s.table_env_stride = h->table_per_env ? (long long)D * D : 0;
     s.env_offset = h->env_offset;
@@ -496,6 +517,7 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     h->D = 1 + cfg->num_cues + 2 * cfg->num_due_pairs;
     h->Nmax = nmax;
     h->N = 0;
+    h->num_cus = prop.multiProcessorCount;
 #define CREATE_TRY(expr)                                                                       \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -508,6 +530,7 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     h->stream = h->own_stream;
     CREATE_TRY(hipMalloc(&h->rec, (size_t)3 * h->Nmax * 16));
     CREATE_TRY(hipMalloc(&h->lpos, (size_t)h->B * h->Nmax * 16));
+    CREATE_TRY(hipMalloc(&h->act_cols, (size_t)h->Nmax * 4));
     CREATE_TRY(hipMalloc(&h->status, 4));
     CREATE_TRY(hipMemset(h->status, 0, 4));
 #undef CREATE_TRY
@@ -525,6 +548,7 @@ int d2d_destroy(d2d_handle* h) {
         if (bf.ptr && bf.owned) hipFree(bf.ptr);
     if (h->rec) hipFree(h->rec);
     if (h->lpos) hipFree(h->lpos);
+    if (h->act_cols) hipFree(h->act_cols);
     if (h->host_out_dev) hipFree(h->host_out_dev);
     if (h->host_out_pinned) hipHostFree(h->host_out_pinned);
     if (h->host_in_dev) hipFree(h->host_in_dev);
@@ -713,6 +737,10 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
         case D2D_TUNE_OBS_GRID:
             if (value < 0 || value % 8) return fail(D2D_ERR_INVALID, "obs grid must be a non-negative multiple of 8");
             h->tune_obs_grid = value;
+            break;
+        case D2D_TUNE_STEP_PREFETCH:
+            if (value < -1) return fail(D2D_ERR_INVALID, "prefetch distance must be >= -1");
+            h->tune_step_prefetch = value;
             break;
         case D2D_TUNE_STEP_WALK:
             if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "walk must be -1, 0 or 1");

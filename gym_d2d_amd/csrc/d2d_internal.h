@@ -34,12 +34,13 @@ struct StepArgs {
     unsigned off_mask;
     int action_mode;         // 0: raw int actions (a // P, a % P)   1: explicit rb / pwr
     int act_stride;          // columns of the action array(s): N - n_fixed in mode 0, N in mode 1
-    int col_mode;            // 0: fixed links are exactly the first n_fixed links (column = link - n_fixed)   1: column from the record
+    int col_mode;            // 0: fixed links are exactly the first n_fixed links (column = link - n_fixed)   1: column from act_cols
     int n_fixed;
     int tpe;                 // threads per env (multiple of 64, <= 1024)
     unsigned tpe_magic;      // ceil(2^20 / tpe): tid / tpe == (tid * tpe_magic) >> 20 for tid < 1024
     float inv_n;             // 1 / N
     int epw;                 // envs per workgroup (epw * tpe <= blockDim)
+    int prefetch_envs;       // software-prefetch distance for the action rows, in envs (multiple of 8 * epw; 0 = off)
     int walk;                // mask walk loop shape: 0 nested (words outside, members inside), 1 flattened
     int reward_fn;
     float reward_param;
@@ -56,6 +57,7 @@ struct StepArgs {
     const int4* rec_a;       // [N]
     const float4* rec_b;     // [N]
     const float4* rec_c;     // [N]
+    const int* act_cols;     // [N] action column of every link (col_mode 1 only; 0 for fixed links)
     const float4* lpos;      // [B, N] (tx_x, tx_y, rx_x, rx_y) of every link, rebuilt when positions / links change
     const float* gain_table; // PL_TABLE: linear gain [D,D] (tx major)
     long long table_env_stride; // 0 or D*D

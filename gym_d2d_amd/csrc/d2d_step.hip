@@ -189,11 +189,13 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
     in.act0 = 0; in.act1 = 0;
     // actions first, branch-free per lane (uniform branches only), so that no join forces a wait on the loads in flight
     if (a.action_mode == 0) {
-        if (a.col_mode == 0 && a.act_stride > 0) {
-            // fixed links are the first n_fixed links (the traffic-model case, CUE links first) or there are none: the
-            // action column follows from the link index alone, so this load does not wait for the record.  A fixed
-            // link reads column 0 and ignores it.
-            const int col = i - a.n_fixed;
+        if (a.act_stride > 0) {
+            // Fixed links are the first n_fixed links (the traffic-model case, CUE links first) or there are none: the
+            // action column follows from the link index alone, so this load waits for nothing.  Arbitrary fixed sets
+            // read their column from a host-built per-link array first (a second hop, but a uniform branch: no join
+            // that would make the compiler wait for every load in flight).  A fixed link reads column 0 and ignores it.
+            int col = i - a.n_fixed;
+            if (a.col_mode != 0) col = a.act_cols[i];
             in.act0 = a.actions[act_row + (unsigned)(col > 0 ? col : 0)];
         }
     } else {
@@ -213,10 +215,7 @@ __device__ __forceinline__ void decode_link(const StepArgs& a, const LinkRaw& in
     if (in.ra.x & D2D_REC_FIXED_BIT) {
         rb = in.ra.z; p = in.ra.w;            // no decode: any power is legal, as in the reference's Action(rb, pwr)
     } else if (a.action_mode == 0) {
-        int act = in.act0;
-        // arbitrary fixed sets (not a prefix of the link list): the action column comes from the record, so this one
-        // load is a dependent second hop - taken here, after pass 0, never in the prologue
-        if (a.col_mode != 0) act = a.actions[act_row + (__float_as_uint(in.rc.w) >> 16)];
+        const int act = in.act0;
         const int P = (int)(__float_as_uint(in.rc.w) & 0xFFFFu);
         const unsigned long long M = (unsigned long long)(unsigned)in.ra.z | ((unsigned long long)(unsigned)in.ra.w << 32);
         int q, r;
@@ -289,7 +288,6 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // join after conditional loads makes the compiler wait for all of them right here.
     const unsigned b_ld = ABL(128) ? 0u : (unsigned)(active ? b : a.B - 1);
     const LinkRaw first = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || lt < N ? lt : N - 1);
-
     // ---- pass 0: clear masks and flags
     const bool want_masks = W > 0 && !ABL(4);
     if (active) {
@@ -298,7 +296,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (lt < 4) s.flags[lt] = 0;
         if (lt < 16) s.red[lt] = 0.0f;
     }
+    // nothing that consumes a loaded value may be scheduled above this barrier: the wave would sit on the HBM round trip
+    // before pass 0 instead of behind it
+    __builtin_amdgcn_sched_barrier(0);
     if (!ABL(64)) __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     if (ABL(256)) {                       // diagnostic: launch + prologue loads + pass 0 only
         if (first.act0 == 0x7fffffff && first.pos.x == 1.2345f && first.rb_.x == first.rc.x && first.ra.y == 77) a.env_flags[b] = 1;
         return;
@@ -334,6 +336,19 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     if (ABL(512)) {                       // diagnostic: everything up to the end of pass 1
         if (me0.z == 1.2345f) a.env_flags[b] = 1;
         return;
+    }
+
+    // Software prefetch, issued once this env's own loads have landed (so no wait for them can catch it): touch the
+    // action row of the env that the workgroup `prefetch_envs` later will own - a multiple of 8, so it lands in the L2 of
+    // the XCD that will read it (round-robin dispatch).  Fresh actions are the one input that is never cache resident, and
+    // with four 512-thread workgroups per CU an HBM miss at the head of every workgroup is exposed four rounds deep
+    // (+7 us at 4096 x 512: profiles/r2_action_prefetch.txt).  The value is consumed by a never-true test at the very end.
+    int pf = 0;
+    if (a.prefetch_envs > 0 && a.action_mode == 0 && a.act_stride > 0) {
+        const int bq = b + a.prefetch_envs;
+        const int bp = bq < a.B ? bq : a.B - 1;                         // clamped, not branched around (a join would wait)
+        const int col = lt < a.act_stride ? lt : a.act_stride - 1;
+        pf = a.actions[(unsigned)bp * (unsigned)a.act_stride + (unsigned)col];
     }
 
     const float* gtab = MODE == PL_TABLE ? a.gain_table + (size_t)b * a.table_env_stride : nullptr;
@@ -514,6 +529,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), (unsigned long long)(wsum * 4294967296.0f));
             if (violated) atomicOr(&s.flags[1], 1);
         }
+        // consume the prefetched word; tied to a value that exists only now, so the load is not waited for earlier
+        // (flags[3] is scratch: the test's outcome changes nothing)
+        if (pf == (__float_as_int(cap_part) | (int)0x80000000)) atomicOr(&s.flags[3], 1);
         if (lane == 0) ticket = atomicAdd(&s.flags[2], 1);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket == (TPE >> 6) - 1) {
@@ -577,6 +595,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         __syncthreads();
     }
 
+    if (pf == (__float_as_int(cap_part) | (int)0x80000000)) atomicOr(&s.flags[3], 1);   // consume the prefetched word (late)
     if (active && lt == 0) a.env_flags[b] = s.flags[0];
 
     // ---- pass 4 (small N only): LinearObs expansion of this workgroup's envs, obs_fn.py:43-53.  Every thread of the
