@@ -90,7 +90,6 @@ struct d2d_handle {
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
-    int tune_obs_grid = 0;
     int num_cus = 0;
     int tune_step_prefetch = -1;                     // action prefetch distance in envs: -1 auto, 0 off
     int tune_step_epw = 0, tune_step_block = 0, tune_step_fuse = -1, tune_step_ablate = 0, tune_step_walk = -1;
@@ -290,7 +289,6 @@ void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float*
     o.nontemporal = h->tune_nt;
     o.block = block;
     o.variant = h->tune_variant;
-    o.grid = h->tune_obs_grid;
     o.table = table;
     o.obs = obs;
     *out = o;
@@ -733,10 +731,6 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
         case D2D_TUNE_STEP_BLOCK:
             if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "block must be a multiple of 64 in [64,1024]");
             h->tune_step_block = value;
-            break;
-        case D2D_TUNE_OBS_GRID:
-            if (value < 0 || value % 8) return fail(D2D_ERR_INVALID, "obs grid must be a non-negative multiple of 8");
-            h->tune_obs_grid = value;
             break;
         case D2D_TUNE_STEP_PREFETCH:
             if (value < -1) return fail(D2D_ERR_INVALID, "prefetch distance must be >= -1");

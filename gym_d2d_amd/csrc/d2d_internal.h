@@ -90,7 +90,6 @@ struct ObsArgs {
     int nontemporal;
     int block;               // threads per workgroup (0 -> 256)
     int variant;             // 0: T staged in LDS   1: T read straight from global (A/B)
-    int grid;                // 0: one workgroup per slab; > 0: persistent grid of that many workgroups (multiple of 8)
     const float* table;      // [B,N,6]
     float* obs;              // [B,N,6N]
 };

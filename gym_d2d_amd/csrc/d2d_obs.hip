@@ -31,23 +31,19 @@ template <int VEC, bool NT>
 __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     extern __shared__ __align__(16) float t_flat[];          // [6N]
     const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
-    const unsigned row_floats = 6u * N;
-    const unsigned total_blocks = (unsigned)a.B * (unsigned)a.chunks;
-    // grid == total_blocks: one slab per workgroup.  A smaller (persistent) grid walks slabs vb, vb + gridDim, ... in the
-    // same order the dispatcher would have issued them (D2D_TUNE_OBS_GRID; gridDim % 8 == 0 keeps a slab's XCD).
-    for (unsigned vb = blockIdx.x; vb < total_blocks; vb += gridDim.x) {
     unsigned env, chunk;
     if (a.xcd_remap) {
         // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give them the chunks of ONE env (G = 1), or
         // of G envs interleaved chunk by chunk (G = xcd_remap > 1: more independent write fronts per XCD)
-        const unsigned bid = vb, lane8 = bid & 7u, rest = bid >> 3, G = (unsigned)a.xcd_remap;
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3, G = (unsigned)a.xcd_remap;
         const unsigned per_group = a.chunks * G, group = rest / per_group, within = rest % per_group;
         chunk = within / G;
         env = (group * G + within % G) * 8u + lane8;
     } else {
-        env = vb / a.chunks;
-        chunk = vb % a.chunks;
+        env = blockIdx.x / a.chunks;
+        chunk = blockIdx.x % a.chunks;
     }
+    const unsigned row_floats = 6u * N;
 
     // stage T[env] (coalesced; 8-byte granules are always aligned because 6N is even)
     {
@@ -80,8 +76,6 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
             f32x2* p = reinterpret_cast<f32x2*>(out + (size_t)idx * 2);
             if (NT) __builtin_nontemporal_store(v, p); else *p = v;
         }
-    }
-    if (vb + gridDim.x < total_blocks) __syncthreads();      // t_flat is re-staged for the next slab
     }
 }
 
@@ -121,9 +115,7 @@ __global__ __launch_bounds__(1024) void obs_expand_direct_kernel(const ObsArgs a
 
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.N * 6 * sizeof(float);
-    unsigned blocks = (unsigned)a.B * (unsigned)a.chunks;
-    if (a.grid > 0 && (unsigned)a.grid < blocks && a.variant != 1) blocks = (unsigned)a.grid;
-    dim3 grid(blocks), block(a.block > 0 ? a.block : 256);
+    dim3 grid((unsigned)a.B * (unsigned)a.chunks), block(a.block > 0 ? a.block : 256);
     if (a.variant == 1 && a.vec == 4) {
         hipLaunchKernelGGL(obs_expand_direct_kernel, grid, block, 0, stream, a);
         return hipGetLastError();

@@ -176,9 +176,7 @@ typedef enum d2d_tuning {
     D2D_TUNE_STEP_BLOCK = 7,       /* threads per step workgroup (>= envs * threads/env); 0 = auto   */
     D2D_TUNE_STEP_FUSE_OBS = 8,    /* LinearObs expansion inside the step launch: 1 on, 0 off,
                                       -1 = auto (on for small N, where two launches are latency bound) */
-    D2D_TUNE_OBS_GRID = 11,        /* obs expansion: 0 (default) one workgroup per slab; > 0: a persistent grid of
-                                      that many workgroups (multiple of 8) walking the slabs in dispatch order   */
-    D2D_TUNE_STEP_PREFETCH = 12,   /* software-prefetch distance of the action rows, in envs: -1 = auto (the envs
+    D2D_TUNE_STEP_PREFETCH = 11,   /* software-prefetch distance of the action rows, in envs: -1 = auto (the envs
                                       resident on the chip at once), 0 = off                                    */
     D2D_TUNE_STEP_WALK = 10,       /* mask walk loop shape: 0 nested (words / members), 1 flattened; -1 = auto */
     D2D_TUNE_STEP_ABLATE = 9,      /* DIAGNOSTIC builds only (D2D_BUILD_DIAG=1), the one key that DOES change
