@@ -304,10 +304,14 @@ def worker(args):
         from gym_d2d_amd.distributed import StepGatherer
         gatherer = StepGatherer(b, n, dev)
 
-    # Per-launch HIP events cost a few microseconds of queue time each: irrelevant beside a 3.7 ms obs kernel, a
-    # third of the step for the small workload.  There the timed region runs WITHOUT them, and the kernel durations
-    # for the roofline block come from a second, instrumented pass over the same steps right after it.
-    events_in_timed = n > 128
+    # An event pair around ONE launch adds about 3-6 us to what it measures (tools/probes/launch_floor.hip: a single
+    # empty wave reads 6 us) and costs host time per step: irrelevant beside the 3.7 ms obs kernel, 10-30 % of a 17-40 us
+    # step.  So: two kernels per step with the expansion dominant (LinearObs, N > 128) -> per-launch events inside the
+    # timed region.  One kernel per step (compact table, or small N with the expansion fused) -> the timed region runs
+    # without events, and a second pass over the same steps brackets GROUPS of back-to-back launches with one event pair
+    # (on the stream the kernels run on): average launch duration = group time / launches, inter-launch gaps included.
+    events_in_timed = args.obs == 'linear' and n > 128
+    GROUP = 20
 
     def run(k0, k1):
         for k in range(k0, k1):
@@ -338,13 +342,24 @@ def worker(args):
     run(args.warmup, total)
     fence()
     dt = time.perf_counter() - t0
-    if not events_in_timed and not stub:
-        h.profile_reset(); h.profile_enable(True)
-        run(args.warmup, total)
-        fence()
     step_ms, step_n = h.profile_read(0)
     obs_ms, obs_n = h.profile_read(1)
     h.profile_enable(False)
+    if not events_in_timed and not stub:
+        stream = torch.cuda.current_stream(dev)          # VecD2DEnv runs the library's kernels on this stream
+        pairs = []
+        for k0 in range(args.warmup, total, GROUP):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k1 = min(k0 + GROUP, total)
+            e0.record(stream)
+            for k in range(k0, k1):
+                h.step(actions[k].data_ptr())
+            e1.record(stream)
+            pairs.append((e0, e1, k1 - k0))
+        torch.cuda.synchronize(dev)
+        step_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in pairs)
+        step_n = sum(c for _, _, c in pairs)
+        obs_ms, obs_n = 0.0, 0
     flags = env.status_flags()
 
     dist_info = {}
@@ -377,7 +392,7 @@ def worker(args):
         value = agent_steps / dt
         core_bytes = 40.0                      # action 4 + positions 16 + outputs 16 + reward 4
         obs_bytes = 24.0 * n                   # LinearObs materialised: 6N floats per agent
-        fused = args.obs == 'linear' and not obs_n         # small N: the expansion runs inside the step launch
+        fused = args.obs == 'linear' and not events_in_timed   # small N: the expansion runs inside the step launch
         if fused:
             per_launch = b * n * (core_bytes + obs_bytes)
             avg_ms = step_ms / max(step_n, 1)
@@ -394,9 +409,10 @@ def worker(args):
         ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roof.update({'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                      'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': per_launch, 'traffic': None,
-                     'timing': 'HIP events around every launch on the library stream, ' +
-                               ('inside the timed region' if events_in_timed else
-                                'in a second pass over the same steps (the timed region itself runs without events)')})
+                     'timing': ('HIP events around every launch on the library stream, inside the timed region' if events_in_timed
+                                else f'HIP events around groups of {GROUP} back-to-back launches (one kernel per step) on the '
+                                     'library stream, in a second pass over the same steps; the timed region itself runs '
+                                     'without events')})
         if not stub:
             attach_traffic(roof, args, w)
         out = {

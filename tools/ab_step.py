@@ -33,14 +33,27 @@ def emit(rec, out):
 
 
 def timed(h, act, launches, kernel=0):
-    """act: one [B, A] action tensor (re-read every launch: it stays in the Infinity Cache) or a [K, B, A] stack that is
-    walked round-robin - fresh actions every launch, as in a rollout (what bench.py does; +4..7 us at 4096 x 512)."""
-    h.profile_reset(); h.profile_enable(True)
+    """Average GPU time per launch in us: ONE event pair around `launches` back-to-back launches (an event pair around a
+    single launch adds 3-6 us of its own, tools/probes/launch_floor.hip); inter-launch gaps are included.
+    act: one [B, A] action tensor (re-read every launch: it stays in the Infinity Cache) or a [K, B, A] stack that is
+    walked round-robin - fresh actions every launch, as in a rollout (what bench.py does).
+    kernel = 1 keeps the library's per-launch events (two kernels per step: the obs kernel's own time)."""
+    if kernel == 1:
+        h.profile_reset(); h.profile_enable(True)
+        for k in range(launches):
+            h.step((act[k % act.shape[0]] if act.dim() == 3 else act).data_ptr())
+        ms, k = h.profile_read(kernel)
+        h.profile_enable(False)
+        return ms / max(k, 1) * 1e3
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h.step((act[0] if act.dim() == 3 else act).data_ptr())
+    e0.record(stream)
     for k in range(launches):
         h.step((act[k % act.shape[0]] if act.dim() == 3 else act).data_ptr())
-    ms, k = h.profile_read(kernel)
-    h.profile_enable(False)
-    return ms / max(k, 1) * 1e3
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / launches * 1e3
 
 
 def stress(args):
