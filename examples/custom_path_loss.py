@@ -1,5 +1,10 @@
 """A user-defined PathLoss plugin (gym-d2d examples/custom_path_loss.py).  Pass the CLASS in env_config; the env
 evaluates it on the host once per episode for every device pair and the GPU kernels consume the resulting table."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))      # run from a checkout without installing
+
 from math import log10
 
 import gym_d2d_amd

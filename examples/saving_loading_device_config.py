@@ -1,5 +1,10 @@
 """Fix device positions / per-device link budgets across experiments through the reference's JSON format
 (gym-d2d examples/saving_loading_device_config.py)."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))      # run from a checkout without installing
+
 import tempfile
 from pathlib import Path
 

@@ -3,6 +3,11 @@
 Every step returns {agent_id: observation}, takes {agent_id: action} and returns rewards / info keyed the same way.
 `gym` is optional: gym_d2d_amd.make() builds the same env without it.
 """
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))      # run from a checkout without installing
+
 import gym_d2d_amd
 
 env = gym_d2d_amd.make('D2DEnv-v0')

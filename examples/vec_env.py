@@ -1,4 +1,9 @@
 """Thousands of environments per step: the batched API (no counterpart in the reference)."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))      # run from a checkout without installing
+
 import torch
 
 from gym_d2d_amd.envs import VecD2DEnv
