@@ -99,3 +99,54 @@ def test_full_size_reset_properties(big_env):
     x0 = x.clone()
     env.reset()
     assert not torch.equal(env._t['pos_x'], x0)
+
+
+def test_baseline_config_4_at_full_size():
+    """BASELINE.json configs[3] at its stated size: 4096 envs x (256 CUE + 256 DUE pairs, 256 RB), FreeSpacePathLoss through
+    the PathLoss plugin route, a custom array ObsFunction that is NOT a pass-through (own link's six values + the env's mean
+    SINR and the count of links sharing the agent's RB, computed from the step's arrays), Shannon reward through the
+    RewardFunction plugin route, traffic-model CUEs.  Sampled envs against the oracle; layout properties on all of them."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    from gym_d2d_amd.envs.obs_fn import ArrayObsFunction
+    from gym_d2d_amd.envs.reward_fn import ShannonRewardFunction
+    from gym_d2d_amd.path_loss import FreeSpacePathLoss
+    from gym_d2d_amd.spaces import Box
+    if not torch.cuda.is_available():
+        pytest.skip('needs torch + GPU')
+
+    class CrowdingObsFunction(ArrayObsFunction):
+        def get_obs_space(self, cfg):
+            return Box(low=-cfg.cell_radius_m, high=cfg.cell_radius_m, shape=(8,))
+
+        def compute(self, view):
+            same = (view.rb[:, :, None] == view.rb[:, None, :]).sum(dim=2).float()            # links on my RB, me included
+            mean_sinr = view.sinr_db.mean(dim=1, keepdim=True).expand_as(view.sinr_db)
+            return torch.cat([view.table, mean_sinr[..., None], same[..., None]], dim=2)
+
+    env = VecD2DEnv({'num_rbs': R, 'num_cues': C, 'num_due_pairs': P, 'path_loss_model': FreeSpacePathLoss,
+                     'obs_fn': CrowdingObsFunction, 'reward_fn': ShannonRewardFunction}, num_envs=B, cue_actions='traffic')
+    obs = env.reset(seed=11)
+    assert tuple(obs.shape) == (B, N, 8) and env.num_agents == P
+    g = torch.Generator(device=env.device); g.manual_seed(3)
+    due = torch.randint(0, R * 21, (B, P), generator=g, device=env.device, dtype=torch.int32)
+    obs, rew, dones, info = env.step(due)
+    torch.cuda.synchronize()
+    assert env.status_flags() == 0
+    rb, pwr = info['rb'].cpu().numpy(), info['tx_pwr_dbm'].cpu().numpy()
+    assert (rb[:, :C] == np.arange(C) % R).all() and (pwr[:, :C] == 23).all()                 # traffic_model.py:15-22
+    assert (rb[:, C:] == due.cpu().numpy() // 21).all() and (pwr[:, C:] == due.cpu().numpy() % 21).all()
+    assert torch.equal(obs[:, :, :6], env._t['table'])
+    assert torch.allclose(obs[:, :, 6], info['sinr_db'].mean(dim=1, keepdim=True).expand(B, N))
+    pos = env.simulator.positions().astype(np.float64)
+    tx, rx, ty = default_links(C, P)
+    ids, cfgs, is_bs = orc.device_configs(C, P)
+    cols = orc.device_columns(cfgs, is_bs)
+    sample = np.arange(0, B, 331)
+    st = orc.step(pos[sample], tx, rx, rb[sample], pwr[sample], cols, orc.PathLossSpec('log_distance', 2.1, ple=2.0), chunk=4)
+    for f in ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps'):
+        assert rel_err(info[f].cpu().numpy()[sample], st[f]) <= TOL, f
+    assert rel_err(rew.cpu().numpy()[sample], orc.reward_shannon(st['sinr_db'])) <= TOL
+    counts = (rb[sample][:, :, None] == rb[sample][:, None, :]).sum(axis=2)
+    assert (obs[:, :, 7].cpu().numpy()[sample] == counts).all()
+    env.close()
