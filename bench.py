@@ -319,8 +319,8 @@ def worker(args):
             if new_episode:                              # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
                 h.reset_positions(1234, k // 10)
             h.step(actions[k].data_ptr())
-            if gatherer is not None and (new_episode or k == k0):
-                gatherer.gather_positions(env._t['table'])      # position columns only change at reset
+            if gatherer is not None and (new_episode or k == 0):
+                gatherer.gather_positions(env._t['table'])      # position columns only change at reset (not per step)
             if gatherer is not None:
                 gatherer.launch(env._t['reward'], env._t['table'])
         if gatherer is not None:
