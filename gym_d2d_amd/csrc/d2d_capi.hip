@@ -92,7 +92,7 @@ struct d2d_handle {
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
     int num_cus = 0;
     int tune_step_prefetch = -1;                     // action prefetch distance in envs: -1 auto, 0 off
-    int tune_step_epw = 0, tune_step_block = 0, tune_step_fuse = -1, tune_step_ablate = 0, tune_step_walk = -1;
+    int tune_step_epw = 0, tune_step_block = 0, tune_step_fuse = -1, tune_step_ablate = 0, tune_step_walk = -1, tune_step_lpt = -1;
     // d2d_step_host: packed device block + pinned host mirrors
     void* host_out_dev = nullptr; size_t host_out_bytes = 0;
     void* host_out_pinned = nullptr;
@@ -320,23 +320,34 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // workgroup (N = 50: four 64-thread envs in 256 threads), and for small N the LinearObs expansion runs inside the
     // same launch, streamed by all threads of the workgroup - two launches of a few microseconds each are bound by
     // launch latency, not by HBM.
-    int tpe = h->tune_step_threads > 0 ? h->tune_step_threads : ((N + 63) / 64) * 64;
+    // lpt = links per thread held in registers (1 or 2; 0 = strided beyond 2 x 1024 links); tpe = threads per env
+    int lpt = h->tune_step_lpt > 0 ? h->tune_step_lpt : 1;
+    int tpe;
+    if (h->tune_step_threads > 0) {
+        tpe = h->tune_step_threads;
+        lpt = N <= tpe ? 1 : (N <= 2 * tpe ? 2 : 0);
+    } else {
+        tpe = (((N + lpt - 1) / lpt + 63) / 64) * 64;
+        if (tpe > 1024) { lpt = 2; tpe = (((N + 1) / 2 + 63) / 64) * 64; }
+        if (tpe > 1024) { lpt = 0; tpe = 1024; }
+    }
     if (tpe > 1024) tpe = 1024;
     if (tpe < 64) tpe = 64;
-    const bool single = N <= tpe;
     int fuse = 0;
     if (h->obs_mode == D2D_OBS_LINEAR) {
         const bool want = h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128;
         if (want) fuse = (6 * N) % 4 == 0 ? 4 : 2;
     }
-    // per-RB membership masks: u32 words, one link per thread (N <= 1024: the summary word names up to 32 mask words)
+    // per-RB membership masks: u32 words, every link of the env in some thread's registers, N <= 1024 (the 32-bit summary
+    // word names up to 32 mask words)
     int W = 0;
-    if (h->bucketing && single) {
+    if (h->bucketing && lpt > 0 && N <= 1024) {
         W = (N + 31) / 32;
-        if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse) > 96 * 1024) W = 0;
+        if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode) > 96 * 1024) W = 0;
     }
-    d2d::step_lds_layout(N, s.R, W, fuse, &s.off_mask, &s.lds_env);
-    const size_t env_lds = s.lds_env;
+    s.lpt = lpt;
+    d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, &s.lds);
+    const size_t env_lds = s.lds.env_bytes;
     if (env_lds > 160 * 1024) return fail(D2D_ERR_UNSUPPORTED, "links per env exceed the LDS staging capacity");
     int epw = h->tune_step_epw;
     if (epw <= 0) epw = tpe >= 256 ? 1 : 256 / tpe;
@@ -735,6 +746,10 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
         case D2D_TUNE_STEP_PREFETCH:
             if (value < -1) return fail(D2D_ERR_INVALID, "prefetch distance must be >= -1");
             h->tune_step_prefetch = value;
+            break;
+        case D2D_TUNE_STEP_LPT:
+            if (value != -1 && value != 1 && value != 2) return fail(D2D_ERR_INVALID, "links per thread must be -1 (auto), 1 or 2");
+            h->tune_step_lpt = value;
             break;
         case D2D_TUNE_STEP_WALK:
             if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "walk must be -1, 0 or 1");

@@ -26,12 +26,17 @@ enum PlMode : int {
 #define D2D_REC_TYPE_MASK 0xF
 #define D2D_REC_FIXED_BIT (1 << 28)
 
+// Byte offsets of one env's LDS arrays (step_lds_layout): only what the configuration reads back is allocated.
+struct StepLds {
+    unsigned aux, rx, sinr, sh, expo, tflat, mask, env_bytes;
+};
+
 struct StepArgs {
     // geometry
     int B, N, R, D;
     int mask_words;          // ceil(N/32): u32 words per RB membership mask (0 -> all-pairs path)
-    unsigned lds_env;        // LDS bytes per env and byte offset of the mask region inside it (step_lds_layout)
-    unsigned off_mask;
+    int lpt;                 // links per thread held in registers: 1, 2, or 0 = strided
+    StepLds lds;             // LDS layout of one env
     int action_mode;         // 0: raw int actions (a // P, a % P)   1: explicit rb / pwr
     int act_stride;          // columns of the action array(s): N - n_fixed in mode 0, N in mode 1
     int col_mode;            // 0: fixed links are exactly the first n_fixed links (column = link - n_fixed)   1: column from act_cols
@@ -97,8 +102,8 @@ struct ObsArgs {
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream);
-size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs);
-void step_lds_layout(int N, int R, int mask_words, int fuse_obs, unsigned* off_mask, unsigned* env_bytes);
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode);
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, StepLds* out);
 hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);
 hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const int4* rec_a, int B, int N, int D,
                                  float4* lpos, hipStream_t stream);

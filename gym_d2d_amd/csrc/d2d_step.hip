@@ -128,27 +128,38 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
     return exp2f(-0.33219280948873623f * a.shadow_chi * z);                     // 10^(-chi z / 10)
 }
 
-// LDS layout of ONE env (byte offsets; the host computes lds_env / off_mask, see step_lds_layout):
-//   0    red[16] f32   wave partial sums            64   flags[4] i32   0: env flags  1: reward violated
+// LDS layout of ONE env (byte offsets, all computed on the host by step_lds_layout and passed in StepArgs::lds):
+//   0    red[16] f32   wave partial sums            64   flags[4] i32   0: env flags  1: reward violated  2: ticket
 //   80   link[N] float4  tx_x, tx_y, effective tx power (mW, incl. tx side of the PL constant), rb bits
-//   +16N rx[N] float2 (strided links only)   +24N sinr[N]   +28N sh[N]   +32N expo[N]   +36N aux[N] (tx_dev | type << 24)
-//   +40N tflat[6N] f32 (fused obs expansion only)
+//   then ONLY what the configuration reads back from LDS:
+//        aux[N] i32 (tx_dev | type << 24)                       always (all-pairs fallback, table route)
+//        rx[N] float2                                           strided links only (LPT == 0)
+//        sinr[N], sh[N] f32                                     Shannon / CueSinrShannon rewards
+//        expo[N] f32                                            power-law / shadowing path loss
+//        tflat[6N] f32                                          fused obs expansion
 //   off_mask: mask[W][R] u32 per-RB membership, word-major (lanes with different RBs hit different banks),
 //             side[W] u32 sidelink membership, summ[R] u32 (bit w set <=> mask[w][rb] != 0)
+// At N = 512, R = 256, inverse-square path loss, SystemCapacity: 10.3 KB + 17.4 KB masks = 27.7 KB per env.
 #define LDS_HEAD_BYTES 80u
 
-void step_lds_layout(int N, int R, int mask_words, int fuse_obs, unsigned* off_mask, unsigned* env_bytes) {
-    unsigned bytes = LDS_HEAD_BYTES + (unsigned)N * 40u + (fuse_obs ? (unsigned)N * 24u : 0u);
-    bytes = (bytes + 7u) & ~7u;
-    *off_mask = bytes;
-    if (mask_words > 0) bytes += ((unsigned)R * mask_words + mask_words + (unsigned)R) * 4u;
-    *env_bytes = (bytes + 15u) & ~15u;
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, StepLds* out) {
+    unsigned off = LDS_HEAD_BYTES + (unsigned)N * 16u;
+    out->aux = off; off += (unsigned)N * 4u;
+    out->rx = off; if (lpt == 0) off += (unsigned)N * 8u;
+    out->sinr = off; out->sh = off + (unsigned)N * 4u; if (reward_fn >= 2) off += (unsigned)N * 8u;
+    out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW) off += (unsigned)N * 4u;
+    off = (off + 7u) & ~7u;
+    out->tflat = off; if (fuse_obs) off += (unsigned)N * 24u;
+    off = (off + 15u) & ~15u;                            // the mask region is cleared with 16-byte stores
+    out->mask = off;
+    if (mask_words > 0) off += ((unsigned)R * mask_words + mask_words + (unsigned)R) * 4u;
+    out->env_bytes = (off + 15u) & ~15u;
 }
 
-size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs) {
-    unsigned off, bytes;
-    step_lds_layout(N, R, mask_words, fuse_obs, &off, &bytes);
-    return bytes;
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode) {
+    StepLds l;
+    step_lds_layout(N, R, mask_words, fuse_obs, lpt, reward_fn, mode, &l);
+    return l.env_bytes;
 }
 
 struct Smem {
@@ -156,18 +167,18 @@ struct Smem {
     unsigned* mask; unsigned* side; unsigned* summ;
 };
 
-__device__ __forceinline__ Smem carve(unsigned char* base, unsigned N, unsigned R, unsigned W, unsigned off_mask) {
+__device__ __forceinline__ Smem carve(unsigned char* base, const StepLds& l, unsigned R, unsigned W) {
     Smem s;
     s.red = reinterpret_cast<float*>(base);
     s.flags = reinterpret_cast<int*>(base + 64);
     s.link = reinterpret_cast<float4*>(base + LDS_HEAD_BYTES);
-    s.rx = reinterpret_cast<float2*>(base + LDS_HEAD_BYTES + 16u * N);
-    s.sinr = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 24u * N);
-    s.sh = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 28u * N);
-    s.expo = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 32u * N);
-    s.aux = reinterpret_cast<int*>(base + LDS_HEAD_BYTES + 36u * N);
-    s.tflat = reinterpret_cast<float*>(base + LDS_HEAD_BYTES + 40u * N);
-    s.mask = reinterpret_cast<unsigned*>(base + off_mask);
+    s.aux = reinterpret_cast<int*>(base + l.aux);
+    s.rx = reinterpret_cast<float2*>(base + l.rx);
+    s.sinr = reinterpret_cast<float*>(base + l.sinr);
+    s.sh = reinterpret_cast<float*>(base + l.sh);
+    s.expo = reinterpret_cast<float*>(base + l.expo);
+    s.tflat = reinterpret_cast<float*>(base + l.tflat);
+    s.mask = reinterpret_cast<unsigned*>(base + l.mask);
     s.side = s.mask + R * W;
     s.summ = s.side + W;
     return s;
@@ -253,19 +264,24 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
     return f < 6u ? head + f : (f < head + 6u ? f - 6u : f);
 }
 
-// SINGLE = every thread owns at most one link (N <= tpe, the normal case up to 1024 links): the per-link loops
-//          collapse to a single body.
-// FULL   = SINGLE, one env per workgroup and N == blockDim: every lane owns exactly one link of an existing env, so
-//          no lane predication (exec-mask save / restore on the scalar pipe) is generated anywhere outside the walk.
-#define FOR_MY_LINKS(i) for (int i = lt, go_ = 1; go_ && (FULL || (active && i < N)); i += TPE, go_ = !SINGLE)
+// LPT  = links per thread held in registers: 1 (thread = link, N <= tpe), 2 (links lt and lt + tpe: half the waves per
+//        env, two independent dependency chains per wave), 0 = strided (N > 2 * 1024: records re-read per link).
+// FULL = LPT > 0, one env per workgroup and N == LPT * blockDim: every lane owns exactly LPT links of an existing env, so
+//        no lane predication (exec-mask save / restore on the scalar pipe) is generated anywhere outside the walk.
+#define FOR_MY_LINKS(u, i)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < (LPT > 0 ? LPT : 0x7fffffff); ++u)                \
+        if (const int i = lt + u * TPE; !(FULL || (active && i < N))) { if (LPT == 0) break; } else
+#define KEPT(u) (LPT > 0 ? (u) : 0)                /* register slot of link u (strided kernels keep only their first) */
+#define IN_REGS(u) (LPT > 0 || (u) == 0)
 
 #ifndef D2D_STEP_ABLATE
 #define D2D_STEP_ABLATE 0       /* diagnostic build: honour StepArgs::ablate (tools/ab_step.py ablate) */
 #endif
 #define ABL(bit) (D2D_STEP_ABLATE && (a.ablate & (bit)))
 
-template <int MODE, bool SINGLE, bool FULL>
+template <int MODE, int LPT, bool FULL>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
+    constexpr int KEEP = LPT > 0 ? LPT : 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int N = a.N, R = a.R, D = a.D, W = a.mask_words, TPE = a.tpe;
     const int tid = threadIdx.x;
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // element offsets fit 32 bits (the host refuses B * N * 6 >= 2^31): one VGPR offset + SGPR base per access
     const unsigned row = (unsigned)b * (unsigned)N;
     const unsigned act_row = (unsigned)b * (unsigned)a.act_stride;
-    Smem s = carve(smem_raw + (FULL ? 0u : (unsigned)(e < a.epw ? e : 0) * a.lds_env), N, R, W, a.off_mask);
+    Smem s = carve(smem_raw + (FULL ? 0u : (unsigned)(e < a.epw ? e : 0) * a.lds.env_bytes), a.lds, R, W);
     if (ABL(1024)) {                      // diagnostic: workgroup launch only
         if (tid == 4095) a.env_flags[b] = 1;
         return;
@@ -287,12 +303,21 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // Inactive lanes (lt >= N, spare env slots) load a clamped duplicate instead of branching around the loads: a
     // join after conditional loads makes the compiler wait for all of them right here.
     const unsigned b_ld = ABL(128) ? 0u : (unsigned)(active ? b : a.B - 1);
-    const LinkRaw first = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || lt < N ? lt : N - 1);
+    LinkRaw first[KEEP];
+#pragma unroll
+    for (int u = 0; u < KEEP; ++u) {
+        const int i = lt + u * TPE;
+        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1);
+    }
     // ---- pass 0: clear masks and flags
     const bool want_masks = W > 0 && !ABL(4);
     if (active) {
-        if (want_masks)
-            for (int k = lt; k < R * W + W + R; k += TPE) s.mask[k] = 0u;      // masks + sidelink words + summaries
+        if (want_masks) {
+            // masks + sidelink words + summaries, 16 bytes per store (the region is 16-byte aligned and padded)
+            uint4* m16 = reinterpret_cast<uint4*>(s.mask);
+            const int n16 = (R * W + W + R + 3) >> 2;
+            for (int k = lt; k < n16; k += TPE) m16[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
         if (lt < 4) s.flags[lt] = 0;
         if (lt < 16) s.red[lt] = 0.0f;
     }
@@ -302,28 +327,30 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     if (!ABL(64)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (ABL(256)) {                       // diagnostic: launch + prologue loads + pass 0 only
-        if (first.act0 == 0x7fffffff && first.pos.x == 1.2345f && first.rb_.x == first.rc.x && first.ra.y == 77) a.env_flags[b] = 1;
+        if (first[0].act0 == 0x7fffffff && first[KEEP - 1].pos.x == 1.2345f && first[0].rb_.x == first[0].rc.x && first[0].ra.y == 77) a.env_flags[b] = 1;
         return;
     }
 
     // ---- pass 1: decode + stage the transmitter side of every link
-    float4 me0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    FOR_MY_LINKS(i) {
-        const LinkRaw in = i == lt ? first : load_link(a, row, act_row, i);
+    float4 me0[KEEP];
+#pragma unroll
+    for (int u = 0; u < KEEP; ++u) me0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    FOR_MY_LINKS(u, i) {
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i);
         int rb, p;
         decode_link(a, in, act_row, rb, p);
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(p) * in.rb_.x, __int_as_float(rb));
         s.link[i] = tuple;
-        if (!SINGLE) s.rx[i] = make_float2(in.pos.z, in.pos.w);
+        if (LPT == 0) s.rx[i] = make_float2(in.pos.z, in.pos.w);
         s.aux[i] = in.ra.x & 0x0FFFFFFF;                                 // tx_dev | link_type << 24
-        if (i == lt) me0 = tuple;                                        // own link stays in registers for pass 2
+        if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
         if (a.rb_out && !ABL(32)) { a.rb_out[row + (unsigned)i] = rb; a.pwr_out[row + (unsigned)i] = p; }
         if (want_masks && !ABL(2)) {
             const unsigned bit = 1u << (i & 31);
             if ((unsigned)rb < (unsigned)R) {
-                atomicOr(&s.mask[(unsigned)(i >> 5) * (unsigned)R + (unsigned)rb], bit);
+                atomicOr(&s.mask[__umul24((unsigned)(i >> 5), (unsigned)R) + (unsigned)rb], bit);
                 atomicOr(&s.summ[rb], 1u << (i >> 5));
             }
             else atomicOr(&s.flags[0], FLAG_RB_OOR);
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     const bool use_masks = want_masks && active && !(s.flags[0] & FLAG_RB_OOR);
     const bool skip_walk = ABL(7);
     if (ABL(512)) {                       // diagnostic: everything up to the end of pass 1
-        if (me0.z == 1.2345f) a.env_flags[b] = 1;
+        if (me0[0].z == 1.2345f) a.env_flags[b] = 1;
         return;
     }
 
@@ -347,8 +374,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     if (a.prefetch_envs > 0 && a.action_mode == 0 && a.act_stride > 0) {
         const int bq = b + a.prefetch_envs;
         const int bp = bq < a.B ? bq : a.B - 1;                         // clamped, not branched around (a join would wait)
-        const int col = lt < a.act_stride ? lt : a.act_stride - 1;
-        pf = a.actions[(unsigned)bp * (unsigned)a.act_stride + (unsigned)col];
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const int i = lt + u * TPE;
+            const int col = i < a.act_stride ? i : a.act_stride - 1;
+            pf ^= a.actions[(unsigned)bp * (unsigned)a.act_stride + (unsigned)col];
+        }
     }
 
     const float* gtab = MODE == PL_TABLE ? a.gain_table + (size_t)b * a.table_env_stride : nullptr;
@@ -358,9 +389,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     float cap_part = 0.0f;
     int my_flags = 0;
     bool violated = false;
-    FOR_MY_LINKS(i) {
-        const LinkRaw in = i == lt ? first : load_link(a, row, act_row, i);   // strided links: records re-read (L2)
-        const float4 me = i == lt ? me0 : s.link[i];
+    FOR_MY_LINKS(u, i) {
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i);   // strided links: records re-read (L2)
+        const float4 me = IN_REGS(u) ? me0[KEPT(u)] : s.link[i];
         const float2 rx = make_float2(in.pos.z, in.pos.w);
         const int rb = __float_as_int(me.w);
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
@@ -385,7 +416,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         if (live == 0u) break;
                         const int w = __builtin_ctz(live);
                         live &= live - 1u;
-                        bits = mrow[(unsigned)w * (unsigned)R];
+                        bits = mrow[__umul24((unsigned)w, (unsigned)R)];
                         if (w == iw) bits &= ~self;                      // .difference({action}), simulator.py:95
                         jbase = w << 5;
                     }
@@ -397,7 +428,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         const float d2 = fmaf(dx, dx, dy * dy);
                         float g;
                         if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
-                        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = min(dmin, __float_as_int(d2)); }
+                        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                         acc = fmaf(o.z, g, acc);                         // simulator.py:97-101, linear mW
                     }
@@ -408,11 +439,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 if (live) {
                     int w = __builtin_ctz(live);
                     live &= live - 1u;
-                    unsigned bits = mrow[(unsigned)w * (unsigned)R];
+                    unsigned bits = mrow[__umul24((unsigned)w, (unsigned)R)];
                     while (true) {
                         const bool more = live != 0u;
                         const int wn = more ? __builtin_ctz(live) : w;
-                        const unsigned bits_n = mrow[(unsigned)wn * (unsigned)R];      // prefetch (a re-read when !more)
+                        const unsigned bits_n = mrow[__umul24((unsigned)wn, (unsigned)R)];   // prefetch (a re-read when !more)
                         if (w == iw) bits &= ~self;                      // .difference({action}), simulator.py:95
                         while (bits) {
                             const int j = (w << 5) + __builtin_ctz(bits);
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                             const float d2 = fmaf(dx, dx, dy * dy);
                             float g;
                             if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
-                            else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = min(dmin, __float_as_int(d2)); }
+                            else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                             if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                             acc = fmaf(o.z, g, acc);                     // simulator.py:97-101, linear mW
                         }
@@ -511,7 +542,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             }
         }
         cap_part += cap;
-        if (dmin == 0) my_flags |= FLAG_ZERO_DISTANCE;
+        // inverse-square gains: a zero distance in the walk shows up as 1/0 = inf in the accumulator (one test instead of a
+        // min per interferer); the own link and the other path-loss modes track the smallest d2 itself
+        if (dmin == 0 || (MODE == PL_INV_SQUARE && !(acc <= 3.0e38f))) my_flags |= FLAG_ZERO_DISTANCE;
         if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
     }
     if (my_flags) atomicOr(&s.flags[0], my_flags);
@@ -522,7 +555,10 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         // ticket (all other waves' atomics precede their ticket in LDS order) finishes the env.  The capacity sum is
         // accumulated in 2^-32 Mbps fixed point, so the 64-bit integer total does not depend on arrival order.
         const int lane = tid & 63;
-        if (a.reward_fn == 2) a.reward[row + (unsigned)tid] = s.sinr[tid] >= a.reward_param ? s.sh[tid] : -1.0f;   // reward_fn.py:52-57
+        if (a.reward_fn == 2) {                                                          // reward_fn.py:52-57
+#pragma unroll
+            for (int u = 0; u < KEEP; ++u) { const int i = tid + u * TPE; a.reward[row + (unsigned)i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f; }
+        }
         int ticket = 0;
         if (a.reward_fn == 1) {
             const float wsum = wave_sum(cap_part);
@@ -558,17 +594,17 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             float total = 0.0f;
             for (int w = 0; w < (TPE + 255) >> 8; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
             const float r = s.flags[1] ? -1.0f : total * a.inv_n;
-            FOR_MY_LINKS(i) a.reward[row + (unsigned)i] = r;
+            FOR_MY_LINKS(u, i) a.reward[row + (unsigned)i] = r;
         }
     } else if (a.reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57
-        FOR_MY_LINKS(i) a.reward[row + (unsigned)i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
+        FOR_MY_LINKS(u, i) a.reward[row + (unsigned)i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
         __syncthreads();
     } else if (a.reward_fn == 3) {
         // CueSinrShannonRewardFunction, reward_fn.py:65-78
         __syncthreads();
-        FOR_MY_LINKS(i) {
-            const int rbi = i == lt ? __float_as_int(me0.w) : __float_as_int(s.link[i].w);
+        FOR_MY_LINKS(u, i) {
+            const int rbi = IN_REGS(u) ? __float_as_int(me0[KEPT(u)].w) : __float_as_int(s.link[i].w);
             bool bad = false;
             if (use_masks) {
                 unsigned live = s.summ[rbi];
@@ -607,7 +643,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         for (int el = 0; el < a.epw; ++el) {
             const int be = blockIdx.x * a.epw + el;
             if (be >= a.B) break;
-            const float* t_flat = reinterpret_cast<const float*>(smem_raw + (unsigned)el * a.lds_env + LDS_HEAD_BYTES + 40u * (unsigned)N);
+            const float* t_flat = reinterpret_cast<const float*>(smem_raw + (unsigned)el * a.lds.env_bytes + a.lds.tflat);
             float* out = a.obs + (size_t)be * N * row_floats;
 #pragma unroll 2
             for (unsigned idx = tid; idx < total; idx += T) {
@@ -672,11 +708,11 @@ hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const i
 }
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream) {
-    const size_t lds = (size_t)a.lds_env * (size_t)a.epw;
+    const size_t lds = (size_t)a.lds.env_bytes * (size_t)a.epw;
     dim3 grid((unsigned)((a.B + a.epw - 1) / a.epw)), block(block_threads);
     hipError_t err = hipSuccess;
-    const bool single = a.N <= a.tpe;
-    const bool full = single && a.epw == 1 && a.N == a.tpe && block_threads == a.tpe && !a.fuse_obs;
+    const int lpt = a.lpt;
+    const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
 #define D2D_LAUNCH_1(M, S, F)                                                                            \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
@@ -689,9 +725,11 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     } while (0)
 #define D2D_LAUNCH(M)                                                                                    \
     do {                                                                                                 \
-        if (full) D2D_LAUNCH_1(M, true, true);                                                           \
-        else if (single) D2D_LAUNCH_1(M, true, false);                                                   \
-        else D2D_LAUNCH_1(M, false, false);                                                              \
+        if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true);                                                  \
+        else if (lpt == 2) D2D_LAUNCH_1(M, 2, false);                                                    \
+        else if (lpt == 1 && full) D2D_LAUNCH_1(M, 1, true);                                             \
+        else if (lpt == 1) D2D_LAUNCH_1(M, 1, false);                                                    \
+        else D2D_LAUNCH_1(M, 0, false);                                                                  \
     } while (0)
     switch (mode) {
         case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;

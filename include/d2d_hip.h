@@ -178,6 +178,7 @@ typedef enum d2d_tuning {
                                       -1 = auto (on for small N, where two launches are latency bound) */
     D2D_TUNE_STEP_PREFETCH = 11,   /* software-prefetch distance of the action rows, in envs: -1 = auto (the envs
                                       resident on the chip at once), 0 = off                                    */
+    D2D_TUNE_STEP_LPT = 12,        /* links per thread held in registers: 1, 2 (half the waves per env), -1 = auto    */
     D2D_TUNE_STEP_WALK = 10,       /* mask walk loop shape: 0 nested (words / members), 1 flattened; -1 = auto */
     D2D_TUNE_STEP_ABLATE = 9,      /* DIAGNOSTIC builds only (D2D_BUILD_DIAG=1), the one key that DOES change
                                       results: bit mask of kernel parts to skip (1 interferer walk, 2 mask
