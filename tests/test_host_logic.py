@@ -246,3 +246,37 @@ def test_philox_known_answers():
     assert f(*([0xffffffff] * 6)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert f(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_reset_action_stream_is_shard_invariant_and_backend_independent():
+    """The random actions of VecD2DEnv.reset (d2d_env.py:54-60) are a pure function of (seed, episode, GLOBAL env, column):
+    NumPy and torch produce the same integers, and any split of the env axis reproduces its slice of the whole batch."""
+    import torch
+    from gym_d2d_amd.envs import _rng
+    highs = [25 * 24] * 3 + [25 * 21] * 4
+    whole = _rng.uniform_ints_numpy(1234, 3, 0, 64, 7, highs)
+    assert whole.dtype == np.int32 and whole.shape == (64, 7)
+    assert (whole >= 0).all() and (whole < np.array(highs)[None, :]).all()
+    assert np.array_equal(_rng.uniform_ints_torch(torch, 1234, 3, 0, 64, 7, highs, 'cpu').numpy(), whole)
+    for first, count in ((0, 16), (16, 16), (40, 24)):
+        assert np.array_equal(_rng.uniform_ints_numpy(1234, 3, first, count, 7, highs), whole[first:first + count])
+    assert not np.array_equal(_rng.uniform_ints_numpy(1234, 4, 0, 64, 7, highs), whole)          # next episode: new draws
+    assert not np.array_equal(_rng.uniform_ints_numpy(1235, 3, 0, 64, 7, highs), whole)
+    big = _rng.uniform_ints_numpy(7, 0, 0, 2048, 64, 256 * 21)
+    assert abs(big.mean() / (256 * 21) - 0.5) < 0.01 and len(np.unique(big)) > 5000
+
+
+def test_make_action_equals_the_dataclass_constructor():
+    """actions.make_action is Action(...) without the frozen dataclass's five object.__setattr__ calls: same fields, same
+    equality / hash (Actions.get_actions_by_rb puts them in sets), still frozen."""
+    import dataclasses
+    from gym_d2d_amd.actions import Action, make_action
+    from gym_d2d_amd.device import BaseStation, UserEquipment
+    from gym_d2d_amd.id import Id
+    from gym_d2d_amd.link_type import LinkType
+    tx, rx = UserEquipment(Id('cue00'), {}), BaseStation(Id('mbs'), {})
+    fast, slow = make_action(tx, rx, LinkType.UPLINK, 3, 17), Action(tx, rx, LinkType.UPLINK, 3, 17)
+    assert fast == slow and hash(fast) == hash(slow) and dataclasses.asdict(fast).keys() == dataclasses.asdict(slow).keys()
+    assert (fast.tx, fast.rx, fast.link_type, fast.rb, fast.tx_pwr_dBm) == (tx, rx, LinkType.UPLINK, 3, 17)
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        fast.rb = 4
