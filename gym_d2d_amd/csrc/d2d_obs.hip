@@ -59,6 +59,27 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     const unsigned total = (r1 - r0) * q_per_row;
     float* out = a.obs + ((size_t)env * N + r0) * row_floats;   // contiguous slab of rows [r0, r1)
 
+    if (VEC == 4 && q_per_row == T) {
+        // The default geometry: one thread per float4 column (block == 6N / 4), so q = tid for every row of the slab and
+        // the source selection is two compares against per-thread constants (column f comes from 6i + f if f < 6, from
+        // f - 6 once i >= f / 6, else from f) - no division, no three-way selection per store.
+        const unsigned f0 = tid * 4u, f1 = f0 + 2u;
+        const unsigned t0 = f0 / 6u, t1 = f1 / 6u;
+        const bool own0 = f0 < 6u, own1 = f1 < 6u;
+        f32x4* o4 = reinterpret_cast<f32x4*>(out) + tid;
+        const f32x2* t2 = reinterpret_cast<const f32x2*>(t_flat);
+#pragma unroll 2
+        for (unsigned i = r0; i < r1; ++i) {
+            const unsigned head = 6u * i;
+            const unsigned s0 = own0 ? head + f0 : (i >= t0 ? f0 - 6u : f0);
+            const unsigned s1 = own1 ? head + f1 : (i >= t1 ? f1 - 6u : f1);
+            const f32x2 lo = t2[s0 >> 1], hi = t2[s1 >> 1];
+            const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+            f32x4* p = o4 + (size_t)(i - r0) * T;
+            if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+        }
+        return;
+    }
 #pragma unroll 4
     for (unsigned idx = tid; idx < total; idx += T) {
         const unsigned lr = (unsigned)(((unsigned long long)idx * a.q_magic) >> 40);   // idx / q_per_row

@@ -640,24 +640,52 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     if (!FULL && a.fuse_obs) {
         const unsigned T = blockDim.x, q_per_row = a.obs_q_per_row, total = (unsigned)N * q_per_row;
         const unsigned row_floats = 6u * (unsigned)N;
-        for (int el = 0; el < a.epw; ++el) {
-            const int be = blockIdx.x * a.epw + el;
-            if (be >= a.B) break;
-            const float* t_flat = reinterpret_cast<const float*>(smem_raw + (unsigned)el * a.lds.env_bytes + a.lds.tflat);
-            float* out = a.obs + (size_t)be * N * row_floats;
+        const unsigned RP = T / q_per_row;                  // whole obs rows one pass of the workgroup covers
+        if (a.fuse_obs == 4 && RP >= 1u) {
+            // Fixed (row-in-pass r, float4 column q) per thread: the source of output column f in row i is 6i + f for f < 6
+            // (the agent's own six values), else f - 6 once i >= f / 6 (links before the agent shift by one slot), else f.
+            // Thresholds and both candidates are per-thread constants, so a store costs two compares + selects instead of
+            // a 40-bit multiply-shift division and two three-way selections (the expansion was VALU bound at N = 50).
+            const unsigned r = (unsigned)(((unsigned long long)tid * a.obs_q_magic) >> 40), q = tid - r * q_per_row;
+            const bool worker = r < RP;
+            const unsigned f0 = q * 4u, f1 = f0 + 2u;
+            const unsigned t0 = f0 / 6u, t1 = f1 / 6u;       // by the compiler's multiply-shift: constants of the thread
+            const bool own0 = f0 < 6u, own1 = f1 < 6u;
+            for (int el = 0; el < a.epw; ++el) {
+                const int be = blockIdx.x * a.epw + el;
+                if (be >= a.B) break;
+                const f32x2* t2 = reinterpret_cast<const f32x2*>(smem_raw + (unsigned)el * a.lds.env_bytes + a.lds.tflat);
+                f32x4* out = reinterpret_cast<f32x4*>(a.obs + (size_t)be * N * row_floats) + q;
+                if (worker)
+                    for (unsigned i = r; i < (unsigned)N; i += RP) {
+                        const unsigned head = 6u * i;
+                        const unsigned s0 = own0 ? head + f0 : (i >= t0 ? f0 - 6u : f0);
+                        const unsigned s1 = own1 ? head + f1 : (i >= t1 ? f1 - 6u : f1);
+                        const f32x2 lo = t2[s0 >> 1], hi = t2[s1 >> 1];
+                        const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+                        __builtin_nontemporal_store(v, out + (size_t)i * q_per_row);
+                    }
+            }
+        } else {
+            for (int el = 0; el < a.epw; ++el) {
+                const int be = blockIdx.x * a.epw + el;
+                if (be >= a.B) break;
+                const float* t_flat = reinterpret_cast<const float*>(smem_raw + (unsigned)el * a.lds.env_bytes + a.lds.tflat);
+                float* out = a.obs + (size_t)be * N * row_floats;
 #pragma unroll 2
-            for (unsigned idx = tid; idx < total; idx += T) {
-                const unsigned i = (unsigned)(((unsigned long long)idx * a.obs_q_magic) >> 40);   // idx / q_per_row
-                const unsigned q = idx - i * q_per_row;
-                if (a.fuse_obs == 4) {
-                    const unsigned f = q * 4u;
-                    const f32x2 lo = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(f, i) >> 1];
-                    const f32x2 hi = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(f + 2u, i) >> 1];
-                    const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)idx * 4));
-                } else {
-                    const f32x2 v = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(q * 2u, i) >> 1];
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(out + (size_t)idx * 2));
+                for (unsigned idx = tid; idx < total; idx += T) {
+                    const unsigned i = (unsigned)(((unsigned long long)idx * a.obs_q_magic) >> 40);   // idx / q_per_row
+                    const unsigned q = idx - i * q_per_row;
+                    if (a.fuse_obs == 4) {
+                        const unsigned f = q * 4u;
+                        const f32x2 lo = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(f, i) >> 1];
+                        const f32x2 hi = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(f + 2u, i) >> 1];
+                        const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)idx * 4));
+                    } else {
+                        const f32x2 v = reinterpret_cast<const f32x2*>(t_flat)[obs_src_col(q * 2u, i) >> 1];
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(out + (size_t)idx * 2));
+                    }
                 }
             }
         }
