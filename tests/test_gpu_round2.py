@@ -379,3 +379,27 @@ def test_device_reset_against_the_reference_samplers(native):
         # the few misses must be rejection decisions at the cell edge: the kernel's own position is still legal
         assert (np.hypot(got[..., 0], got[..., 1]) <= c['cell_radius_m'] * (1 + 1e-6)).all()
         sim.handle.close()
+
+
+@pytest.mark.parametrize('shape', [(9, 16, 100, 100), (5, 256, 256, 256), (7, 3, 33, 90)])
+@pytest.mark.parametrize('reward', [1, 2, 3])
+def test_two_links_per_thread_matches_one(native, shape, reward):
+    """D2D_TUNE_STEP_LPT = 2 (links lt and lt + tpe of an env in one thread's registers, half the waves per env): every
+    per-link output is bit-identical to the one-link-per-thread kernel; the SystemCapacity reward differs only by the
+    order in which the capacities are summed (different wave partition), i.e. in its last bits."""
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(native, b, rbs, cues, dues, seed=sum(shape) + reward)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+    h.set_reward(reward, {1: 0.0, 2: -70.0, 3: 0.0}[reward])
+    snaps = {}
+    for lpt in (1, 2):
+        h.set_tuning(native.TUNE_STEP_LPT, lpt)
+        sim.step_arrays(raw)
+        snaps[lpt] = _snapshot(sim, native, False)
+    for buf, ref in snaps[1].items():
+        if buf == 'BUF_REWARD' and reward == 1:
+            assert np.allclose(snaps[2][buf], ref, rtol=1e-6, atol=1e-7)
+        else:
+            assert np.array_equal(snaps[2][buf], ref), buf
+    sim.handle.close()
