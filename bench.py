@@ -208,6 +208,9 @@ def parse_args(argv=None):
     ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,fuse')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST HOOK: no GPU, gloo backend, synthetic per-rank results - exercises only the launcher / gather plumbing')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='TEST HOOK: every rank uses cuda:0 and gloo carries the collectives (RCCL refuses two ranks on one '
+                         'GPU) - the real worker with N > 1 on a one-GPU box; never a measurement')
     return ap.parse_args(argv)
 
 
@@ -241,6 +244,8 @@ def worker(args):
     if stub:
         dev = torch.device('cpu')
     else:
+        if args.share_gpu:
+            local = 0
         if local >= torch.cuda.device_count():
             raise SystemExit(f'rank {rank}: needs GPU {local} but this box exposes {torch.cuda.device_count()}')
         torch.cuda.set_device(local)
@@ -250,7 +255,7 @@ def worker(args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        if stub:
+        if stub or args.share_gpu:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -437,6 +442,8 @@ def worker(args):
         out.update(dist_info)
         if stub:
             out['stub'] = 'CPU plumbing test - not a measurement'
+        if args.share_gpu:
+            out['shared_gpu'] = f'{world} ranks on ONE GPU over gloo: multi-rank correctness test - not a measurement'
         if single_ms is not None:
             out['single_env_step_ms'] = single_ms
         if cpu is not None:

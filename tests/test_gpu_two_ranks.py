@@ -78,3 +78,29 @@ def test_two_ranks_sharing_one_gpu_reproduce_the_single_process_batch(tmp_path):
         assert np.array_equal(got[f'table{k}'], env._t['table'].cpu().numpy()), k
         assert np.array_equal(got[f'obs{k}'], obs.cpu().numpy()), k
     env.close()
+
+
+def test_bench_two_ranks_on_one_gpu_agree_with_one_rank_of_twice_the_envs():
+    """bench.py's real worker with N = 2 (self-launched, both ranks on cuda:0, gloo): the collectives saw 2 ranks, the
+    all-gathered rewards sum to the all-reduced local sums, and that sum is NOT rank-0's sum twice (the shards differ:
+    first_env offsets reach the reset sampler).  The driver's 8-GPU run is this code with RCCL as the transport."""
+    import json
+    import subprocess
+    cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--share-gpu', '--workload', 'default', '--obs', 'table',
+           '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    two = json.loads(lines[0])
+    assert two['n_gpus'] == 2 and two['rccl_ranks'] == 2 and two['allreduce_rank_count'] == 2.0
+    assert two['allgather_envs'] == 128 and two['checksums_agree'] is True and 'shared_gpu' in two
+    assert two['status_flags'] == 0
+    one = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '1', '--force-dist', '--workload', 'default',
+                          '--obs', 'table', '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=600,
+                         env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+    assert one.returncode == 0, one.stderr[-3000:]
+    rank0 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][0])
+    assert abs(two['allgather_reward_checksum'] - 2 * rank0['allgather_reward_checksum']) > 1e-3
