@@ -73,6 +73,7 @@ struct d2d_handle {
     int* act_cols = nullptr;        // [Nmax] action column per link (arbitrary fixed sets)
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
     bool lpos_dirty = true;
+    bool std_layout = false;        // link i < C is (cue i -> mbs), link C + k is (due 2k -> due 2k+1): d2d_reset_positions writes lpos itself
     float* gain_table = nullptr;
     size_t gain_elems = 0;
     int table_per_env = 0;
@@ -202,6 +203,12 @@ int refresh_tables(d2d_handle* h) {
     HIP_TRY(hipMemcpyAsync(h->rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // rec is a stack-lifetime host buffer
     h->col_mode = prefix ? 0 : 1;
+    const int C = h->cfg.num_cues;
+    bool std_layout = N == C + (D - 1 - C) / 2 && D == 1 + C + 2 * (N - C);
+    for (int i = 0; i < N && std_layout; ++i)
+        std_layout = i < C ? (h->host_tx[i] == i + 1 && h->host_rx[i] == 0)
+                           : (h->host_tx[i] == C + 1 + 2 * (i - C) && h->host_rx[i] == C + 2 + 2 * (i - C));
+    h->std_layout = std_layout;
     h->tables_dirty = false;
     h->lpos_dirty = true;                       // the link -> device map may have changed
     return D2D_OK;
@@ -864,10 +871,14 @@ int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const ui
         HIP_TRY(hipStreamSynchronize(h->stream));   // caller's host arrays may go away
         m = h->fixed_mask_dev; xy = h->fixed_xy_dev;
     }
+    // with the standard link list (every uplink and every sidelink, in device order) the sampler writes the per-link
+    // position rows itself; any other list is gathered from POS_X / POS_Y before the next step
+    const bool rows_here = !h->tables_dirty && h->std_layout && h->lpos && h->N > 0;
     HIP_TRY(d2d::launch_reset(h->B, h->D, h->cfg.num_cues, h->cfg.cell_radius_m, h->cfg.d2d_radius_m, seed, episode,
-                              h->env_offset, m, xy, static_cast<float*>(px), static_cast<float*>(py), h->stream));
+                              h->env_offset, m, xy, static_cast<float*>(px), static_cast<float*>(py),
+                              rows_here ? h->lpos : nullptr, h->N, h->stream));
     h->have_pos = true;
-    h->lpos_dirty = true;
+    h->lpos_dirty = !rows_here;
     return D2D_OK;
 }
 

@@ -109,6 +109,6 @@ hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const i
                                  float4* lpos, hipStream_t stream);
 hipError_t launch_reset(int B, int D, int C, float cell_radius, float d2d_radius, unsigned long long seed,
                         unsigned long long episode, unsigned long long env_offset, const unsigned char* fixed_mask,
-                        const float* fixed_xy, float* pos_x, float* pos_y, hipStream_t stream);
+                        const float* fixed_xy, float* pos_x, float* pos_y, float4* lpos, int N, hipStream_t stream);
 
 }  // namespace d2d

@@ -403,3 +403,38 @@ def test_two_links_per_thread_matches_one(native, shape, reward):
         else:
             assert np.array_equal(snaps[2][buf], ref), buf
     sim.handle.close()
+
+
+def test_reset_writes_the_link_position_rows_itself_for_the_standard_link_list(native):
+    """With every uplink and sidelink in device order (the env's own list) d2d_reset_positions fills the per-link rows in
+    the sampler kernel; any other list, or a caller saying positions_changed, goes through the gather kernel.  Same step
+    results, bit for bit - and a reordered link list (gather route) agrees with the standard one link by link."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    cfg = {'num_rbs': 5, 'num_cues': 6, 'num_due_pairs': 7}
+    outs = []
+    for route in ('sampler', 'gather'):
+        env = VecD2DEnv(dict(cfg), num_envs=33)
+        env.reset(seed=77)
+        if route == 'gather':
+            env.simulator.handle.positions_changed()
+        act = torch.randint(0, 5 * 21, (33, 13), device=env.device, dtype=torch.int32,
+                            generator=torch.Generator(device=env.device).manual_seed(5))
+        obs, rew, _, info = env.step(act)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in dict(info, obs=obs, rew=rew).items() if torch.is_tensor(v)})
+        env.close()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    # table columns 0..3 are the link's own tx / rx coordinates: they must be the sampled device positions
+    env = VecD2DEnv(dict(cfg, obs_fn=__import__('gym_d2d_amd.envs.obs_fn', fromlist=['x']).OwnLinkObsFunction), num_envs=33)
+    env.reset(seed=77)
+    act = torch.zeros((33, 13), device=env.device, dtype=torch.int32)
+    env.step(act)
+    torch.cuda.synchronize()
+    t, px, py = env._t['table'].cpu().numpy(), env._t['pos_x'].cpu().numpy(), env._t['pos_y'].cpu().numpy()
+    tx = np.array([i + 1 for i in range(6)] + [7 + 2 * k for k in range(7)])
+    rx = np.array([0] * 6 + [8 + 2 * k for k in range(7)])
+    assert np.array_equal(t[:, :, 0], px[:, tx]) and np.array_equal(t[:, :, 1], py[:, tx])
+    assert np.array_equal(t[:, :, 2], px[:, rx]) and np.array_equal(t[:, :, 3], py[:, rx])
+    env.close()
