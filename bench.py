@@ -204,7 +204,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the per-step all-gather')
     ap.add_argument('--with-reset', action='store_true', help='redraw all device positions every 10 steps (device-side reset)')
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
-    ap.add_argument('--single-env-latency', action='store_true', help='also time the drop-in D2DEnv.step (host dicts), N = 1 only')
+    ap.add_argument('--no-single-env-latency', action='store_true',
+                    help='N = 1 also times the drop-in single-env D2DEnv.step (host dicts in / out); this skips it')
     ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,fuse')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST HOOK: no GPU, gloo backend, synthetic per-rank results - exercises only the launcher / gather plumbing')
@@ -259,6 +260,14 @@ def worker(args):
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    # the path every existing gym-d2d user calls: one env, dicts in / out (d2d_env.py:62-71).  Reported beside the batch
+    # number, never as `value`; timed before the batch env exists so its 26 GB of buffers are not in the picture.
+    single_ms = None
+    if rank == 0 and world == 1 and not args.no_single_env_latency and not stub:
+        single_ms = {'25 CUE + 25 DUE pairs, 25 RB (reference default env)': single_env_latency(25, 25, 25, local)}
+        if (c, p, r) != (25, 25, 25):
+            single_ms[f'{c} CUE + {p} DUE pairs, {r} RB'] = single_env_latency(c, p, r, local)
 
     if w.get('plugin'):
         args.obs = 'table'
@@ -388,10 +397,6 @@ def worker(args):
             dist_info['checksums_agree'] = bool(abs(gsum - dist_info['allreduce_reward_checksum'])
                                                 <= 1e-6 * max(1.0, abs(gsum)))
 
-    single_ms = None
-    if rank == 0 and world == 1 and args.single_env_latency and not stub:
-        single_ms = single_env_latency(c, p, r, local)
-
     if rank == 0:
         agent_steps = b * n * args.steps * world
         value = agent_steps / dt
@@ -495,10 +500,15 @@ def single_env_latency(c, p, r, ordinal, steps=200):
             for _ in range(8)]
     for k in range(5):
         env.step(acts[k % 8])
-    t0 = time.perf_counter()
-    for k in range(steps):
-        env.step(acts[k % 8])
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    import gc
+    gc.collect(); gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for k in range(steps):
+            env.step(acts[k % 8])
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        gc.enable()
     env.close()
     return ms
 

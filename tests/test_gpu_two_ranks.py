@@ -87,7 +87,7 @@ def test_bench_two_ranks_on_one_gpu_agree_with_one_rank_of_twice_the_envs():
     import json
     import subprocess
     cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--share-gpu', '--workload', 'default', '--obs', 'table',
-           '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline']
+           '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-single-env-latency']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
                        env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
     assert r.returncode == 0, r.stderr[-3000:]
@@ -98,7 +98,7 @@ def test_bench_two_ranks_on_one_gpu_agree_with_one_rank_of_twice_the_envs():
     assert two['allgather_envs'] == 128 and two['checksums_agree'] is True and 'shared_gpu' in two
     assert two['status_flags'] == 0
     one = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '1', '--force-dist', '--workload', 'default',
-                          '--obs', 'table', '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline'],
+                          '--obs', 'table', '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-single-env-latency'],
                          capture_output=True, text=True, timeout=600,
                          env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
     assert one.returncode == 0, one.stderr[-3000:]

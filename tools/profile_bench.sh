@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_${tag}_${wl}_${obs}
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-args="--workload $wl --obs $obs --no-cpu-baseline"
+args="--workload $wl --obs $obs --no-cpu-baseline --no-single-env-latency"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $R/bench.py $args --steps $steps --warmup 10 > $out/kt.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $R/bench.py $args --steps 5 --warmup 1 > $out/pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py $args --steps 5 --warmup 1 > $out/pmc_fetch.log 2>&1
