@@ -72,6 +72,19 @@ def main():
            'workload_key': f'{wl}/{obs}', 'source_digest': source_digest(), 'kernels': kernels}
     out = ROOT / 'profiles' / f'{tag}_pmc_{wl}_{obs}.json'
     out.write_text(json.dumps(rec, indent=1))
+    if (wl, obs) == ('stress', 'table'):
+        # the step kernel is 100 % of this mode's step: its own summary under the name VERDICT r1 asked for
+        step = {k: d for k, d in kernels.items() if 'step_kernel' in k}
+        for k, d in step.items():
+            sq = d.get('sq_per_wave', {})
+            d['summary'] = {'SQ_WAIT_ANY / SQ_WAVE_CYCLES': d.get('wait_any_fraction_of_wave_cycles'),
+                            'SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE': d.get('lds_bank_conflict_ratio'),
+                            'VALU per wave': sq.get('SQ_INSTS_VALU'), 'SALU per wave': sq.get('SQ_INSTS_SALU'),
+                            'LDS per wave': sq.get('SQ_INSTS_LDS'), 'VMEM rd / wr per wave': [sq.get('SQ_INSTS_VMEM_RD'), sq.get('SQ_INSTS_VMEM_WR')],
+                            'FETCH (x2 corrected) / WRITE bytes per launch': [2 * 1024 * d.get('FETCH_SIZE_KiB_mean_per_launch', 0.0),
+                                                                             1024 * d.get('WRITE_SIZE_KiB_mean_per_launch', 0.0)],
+                            'algorithmic bytes per launch (4096 x 512 x 64)': 4096 * 512 * 64}
+        (ROOT / 'profiles' / f'{tag}_pmc_step_kernel.json').write_text(json.dumps(dict(rec, kernels=step), indent=1))
     for k, d in kernels.items():
         print(k[:60], {a: (round(b) if isinstance(b, float) else b) for a, b in d.items() if not isinstance(b, dict)})
 
