@@ -73,6 +73,7 @@ struct d2d_handle {
     int* act_cols = nullptr;        // [Nmax] action column per link (arbitrary fixed sets)
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
     bool lpos_dirty = true;
+    unsigned long long* dbg = nullptr;   // diagnostic builds only
     bool std_layout = false;        // link i < C is (cue i -> mbs), link C + k is (due 2k -> due 2k+1): d2d_reset_positions writes lpos itself
     float* gain_table = nullptr;
     size_t gain_elems = 0;
@@ -321,6 +322,13 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
     s.ablate = h->tune_step_ablate;
+    s.dbg = nullptr;
+#if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
+    if (h->tune_step_ablate & 8192) {          // phase stamps: [B workgroups][16 waves][8] u64 (tools/phase_times.py)
+        if (!h->dbg) HIP_TRY(hipMalloc(&h->dbg, (size_t)h->B * 16 * 8 * 8));
+        s.dbg = h->dbg;
+    }
+#endif
     s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : 0;
 
     // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
@@ -564,6 +572,7 @@ int d2d_destroy(d2d_handle* h) {
         if (bf.ptr && bf.owned) hipFree(bf.ptr);
     if (h->rec) hipFree(h->rec);
     if (h->lpos) hipFree(h->lpos);
+    if (h->dbg) hipFree(h->dbg);
     if (h->act_cols) hipFree(h->act_cols);
     if (h->host_out_dev) hipFree(h->host_out_dev);
     if (h->host_out_pinned) hipHostFree(h->host_out_pinned);
@@ -726,6 +735,17 @@ int d2d_set_bucketing(d2d_handle* h, int32_t enabled) {
     return D2D_OK;
 }
 
+#if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
+// diagnostic builds only (not in include/d2d_hip.h): copy the phase stamps of the last step to the host
+extern "C" int d2d_debug_stamps(d2d_handle* h, void* host, size_t bytes) {
+    if (!h || !h->dbg) return fail(D2D_ERR_STATE, "no stamps: set D2D_TUNE_STEP_ABLATE bit 8192 and step first");
+    USE_DEVICE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(host, h->dbg, bytes, hipMemcpyDeviceToHost));
+    return D2D_OK;
+}
+#endif
+
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
@@ -764,7 +784,7 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
             break;
         case D2D_TUNE_STEP_ABLATE:
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
-            h->tune_step_ablate = value & 2047;
+            h->tune_step_ablate = value;
             break;
 #else
             if (value != 0) return fail(D2D_ERR_UNSUPPORTED, "D2D_TUNE_STEP_ABLATE needs the diagnostic build (D2D_BUILD_DIAG=1 python -m gym_d2d_amd.build)");

@@ -51,6 +51,7 @@ struct StepArgs {
     float reward_param;
     int write_table;
     int ablate;              // DIAGNOSTIC builds only (-DD2D_STEP_ABLATE=1): skip parts of the kernel to time the rest
+    unsigned long long* dbg; // DIAGNOSTIC builds only: [workgroup][wave][8] shader-clock stamps at the phase boundaries, or null
     // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)
     int fuse_obs;
     unsigned obs_q_per_row;          // 6N / fuse_obs

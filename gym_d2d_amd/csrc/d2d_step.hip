@@ -278,6 +278,13 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
 #define D2D_STEP_ABLATE 0       /* diagnostic build: honour StepArgs::ablate (tools/ab_step.py ablate) */
 #endif
 #define ABL(bit) (D2D_STEP_ABLATE && (a.ablate & (bit)))
+// diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py)
+#if D2D_STEP_ABLATE
+#define STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0)                                                              \
+        a.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 template <int MODE, int LPT, bool FULL>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     const unsigned row = (unsigned)b * (unsigned)N;
     const unsigned act_row = (unsigned)b * (unsigned)a.act_stride;
     Smem s = carve(smem_raw + (FULL ? 0u : (unsigned)(e < a.epw ? e : 0) * a.lds.env_bytes), a.lds, R, W);
+    STAMP(0);
     if (ABL(1024)) {                      // diagnostic: workgroup launch only
         if (tid == 4095) a.env_flags[b] = 1;
         return;
@@ -324,7 +332,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // nothing that consumes a loaded value may be scheduled above this barrier: the wave would sit on the HBM round trip
     // before pass 0 instead of behind it
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
     if (!ABL(64)) __syncthreads();
+    STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
     if (ABL(256)) {                       // diagnostic: launch + prologue loads + pass 0 only
         if (first[0].act0 == 0x7fffffff && first[KEEP - 1].pos.x == 1.2345f && first[0].rb_.x == first[0].rc.x && first[0].ra.y == 77) a.env_flags[b] = 1;
@@ -357,7 +367,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             if (type == LINK_SIDELINK) atomicOr(&s.side[i >> 5], bit);
         }
     }
+    STAMP(3);
     if (!ABL(64)) __syncthreads();
+    STAMP(4);
     const bool use_masks = want_masks && active && !(s.flags[0] & FLAG_RB_OOR);
     const bool skip_walk = ABL(7);
     if (ABL(512)) {                       // diagnostic: everything up to the end of pass 1
@@ -479,6 +491,14 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             }
         }
 
+        if (D2D_STEP_ABLATE && a.dbg && acc == -1.0f) my_flags |= 1 << 30;   // (never true) pins the stamp behind the walk
+        STAMP(5);
+        if (ABL(16384)) {                    // diagnostic: 64 extra VALU instructions per wave - is the kernel VALU bound?
+            float x0 = me.x, x1 = me.y;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { x0 = fmaf(x0, 1.0001f, 0.5f); x1 = fmaf(x1, 0.9999f, 0.25f); }
+            if (x0 + x1 == 1.2345f) my_flags |= 1 << 29;
+        }
         // own link: simulator.py:93
         const float dx = me.x - rx.x, dy = me.y - rx.y;
         const float d2 = fmaf(dx, dx, dy * dy);
@@ -548,6 +568,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
     }
     if (my_flags) atomicOr(&s.flags[0], my_flags);
+    STAMP(6);
 
     // ---- pass 3: reward
     if (FULL && a.reward_fn != 3) {
@@ -580,6 +601,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             }
             if (lane == 0) a.env_flags[b] = *reinterpret_cast<volatile int*>(&s.flags[0]);
         }
+        STAMP(7);
         return;
     }
     if (a.reward_fn == 1) {
