@@ -376,6 +376,36 @@ def worker(args):
         obs_ms, obs_n = 0.0, 0
     flags = env.status_flags()
 
+    # report the 'core' mode beside the with-obs mode.  Same envs, same actions, obs_fn swapped for the
+    # compact table (what a learner that builds its own features consumes): the step is then the step kernel alone.
+    core = None
+    if world == 1 and rank == 0 and not stub and args.obs == 'linear' and n > 128:
+        h.set_obs_mode(_native.OBS_TABLE)
+        for k in range(args.warmup):
+            h.step(actions[k].data_ptr())
+        torch.cuda.synchronize(dev)
+        t0c = time.perf_counter()
+        for k in range(args.warmup, total):
+            h.step(actions[k].data_ptr())
+        torch.cuda.synchronize(dev)
+        dtc = time.perf_counter() - t0c
+        stream = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(args.warmup, total):
+            h.step(actions[k].data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        k_ms = e0.elapsed_time(e1) / args.steps
+        h.set_obs_mode(_native.OBS_LINEAR)
+        core_bytes_launch = b * n * 64.0
+        core = {'obs_mode': 'table (compact [B, N, 6] obs, no LinearObs expansion)', 'value': b * n * args.steps / dtc,
+                'unit': 'agent-steps/s', 'ms_per_step': dtc / args.steps * 1e3,
+                'roofline': {'kernel': 'step_kernel', 'bound': 'hbm', 'achieved': core_bytes_launch / (k_ms * 1e-3) / 1e9,
+                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': core_bytes_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'avg_launch_ms': k_ms, 'algorithmic_bytes_per_launch': core_bytes_launch,
+                             'timing': f'one HIP event pair around {args.steps} back-to-back launches'}}
+
     dist_info = {}
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -451,6 +481,8 @@ def worker(args):
             out['shared_gpu'] = f'{world} ranks on ONE GPU over gloo: multi-rank correctness test - not a measurement'
         if single_ms is not None:
             out['single_env_step_ms'] = single_ms
+        if core is not None:
+            out['core_mode'] = core
         if cpu is not None:
             out['cpu_baseline'] = cpu
         sys.stdout.flush()
