@@ -17,7 +17,10 @@ rank failed.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the library's stream),
 `cpu_baseline` (the NumPy fp64 oracle timed on this box's host cores on a bounded sample; rank 0, N = 1 only; one
-thread, with the all-core figure beside it) and, for N > 1, `rccl_ranks` + all-reduce / all-gather checksums.
+thread, with the all-core figure beside it) and, for N > 1, `rccl_ranks` + all-reduce / all-gather checksums.  At N = 1
+the line also carries, beside `value` and never as it: `core_mode` (the same envs stepped with the compact-table obs:
+throughput + the step kernel's roofline block) and `single_env_step_ms` (the drop-in single-env
+D2DEnv.step, host dicts in / out, at the reference's default shape and at the workload's).
 """
 import argparse
 import json
