@@ -317,8 +317,8 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.act_stride = action_mode == 0 ? N - h->n_fixed : N;
     s.col_mode = h->col_mode; s.n_fixed = h->n_fixed;
     s.inv_n = 1.0f / (float)N;
-    if ((size_t)h->B * (size_t)N * 6 >= (1ull << 31))
-        return fail(D2D_ERR_UNSUPPORTED, "envs x links per GPU must stay below 2^31 / 6 (32-bit element offsets in the step kernel)");
+    if ((size_t)h->B * (size_t)N * 24 >= (1ull << 32))
+        return fail(D2D_ERR_UNSUPPORTED, "envs x links per GPU must stay below 2^32 / 24 (32-bit byte offsets in the step kernel)");
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
     s.ablate = h->tune_step_ablate;

@@ -38,6 +38,7 @@
 //   * reductions (capacity sum) are xor-butterfly wave reductions + a fixed-order cross-wave sum:
 //     run-to-run deterministic.
 #include "d2d_internal.h"
+#include <type_traits>
 
 namespace d2d {
 
@@ -184,6 +185,17 @@ __device__ __forceinline__ Smem carve(unsigned char* base, const StepLds& l, uns
     return s;
 }
 
+// base + 32-bit BYTE offset: selects to a global access with an SGPR base and ONE VGPR offset, so the 4-byte arrays of an env
+// share a single offset register and no 64-bit address is formed per array (10 v_lshl_add_u64 per link before).  The host
+// keeps B * N * 24 below 2^32 (run_step).
+// The offset is laundered through an empty asm so that its zero-extension happens next to the access: instruction
+// selection works per basic block, and a 64-bit offset pair carried in from another block is added with a v_lshl_add_u64.
+template <class T>
+__device__ __forceinline__ T* at(T* base, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
+}
+
 // Everything the kernel needs about one link, as it comes out of memory.  The loads are INDEPENDENT of one another
 // (no link -> device -> position double hop, no power-table lookup, no per-type constant fetched behind the record):
 // they are issued back to back in the prologue and first used after pass 0's barrier.
@@ -207,16 +219,16 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
             // that would make the compiler wait for every load in flight).  A fixed link reads column 0 and ignores it.
             int col = i - a.n_fixed;
             if (a.col_mode != 0) col = a.act_cols[i];
-            in.act0 = a.actions[act_row + (unsigned)(col > 0 ? col : 0)];
+            in.act0 = *at(a.actions, (act_row + (unsigned)(col > 0 ? col : 0)) * 4u);
         }
     } else {
-        in.act0 = a.rb_in[row + (unsigned)i];
-        in.act1 = a.pwr_in[row + (unsigned)i];
+        in.act0 = *at(a.rb_in, (row + (unsigned)i) * 4u);
+        in.act1 = *at(a.pwr_in, (row + (unsigned)i) * 4u);
     }
     in.ra = a.rec_a[i];
     in.rb_ = a.rec_b[i];
     in.rc = a.rec_c[i];
-    in.pos = a.lpos[row + (unsigned)i];
+    in.pos = *at(a.lpos, (row + (unsigned)i) * 16u);
     return in;
 }
 
@@ -324,7 +336,15 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             // masks + sidelink words + summaries, 16 bytes per store (the region is 16-byte aligned and padded)
             uint4* m16 = reinterpret_cast<uint4*>(s.mask);
             const int n16 = (R * W + W + R + 3) >> 2;
-            for (int k = lt; k < n16; k += TPE) m16[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (FULL) {
+                // whole rounds with a wave-uniform trip count (scalar loop, no exec masking), then one predicated tail
+                int k0 = 0;
+#pragma unroll 1
+                for (; k0 + TPE <= n16; k0 += TPE) m16[lt + k0] = make_uint4(0u, 0u, 0u, 0u);
+                if (lt < n16 - k0) m16[lt + k0] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                for (int k = lt; k < n16; k += TPE) m16[k] = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
         if (lt < 4) s.flags[lt] = 0;
         if (lt < 16) s.red[lt] = 0.0f;
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         s.aux[i] = in.ra.x & 0x0FFFFFFF;                                 // tx_dev | link_type << 24
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
-        if (a.rb_out && !ABL(32)) { a.rb_out[row + (unsigned)i] = rb; a.pwr_out[row + (unsigned)i] = p; }
+        if (a.rb_out && !ABL(32)) { *at(a.rb_out, (row + (unsigned)i) * 4u) = rb; *at(a.pwr_out, (row + (unsigned)i) * 4u) = p; }
         if (want_masks && !ABL(2)) {
             const unsigned bit = 1u << (i & 31);
             if ((unsigned)rb < (unsigned)R) {
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         for (int u = 0; u < KEEP; ++u) {
             const int i = lt + u * TPE;
             const int col = i < a.act_stride ? i : a.act_stride - 1;
-            pf ^= a.actions[(unsigned)bp * (unsigned)a.act_stride + (unsigned)col];
+            pf ^= *at(a.actions, ((unsigned)bp * (unsigned)a.act_stride + (unsigned)col) * 4u);
         }
     }
 
@@ -526,13 +546,14 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float cap = ok ? bw_mhz * sh : 0.0f;                       // simulator.py:150-151
 
         if (!ABL(8)) {
-            a.sinr_db[row + (unsigned)i] = sinr_db;
-            a.snr_db[row + (unsigned)i] = snr_db;
-            a.rate[row + (unsigned)i] = rate;
-            a.cap[row + (unsigned)i] = cap;
+            const unsigned o4 = (row + (unsigned)i) * 4u;
+            *at(a.sinr_db, o4) = sinr_db;
+            *at(a.snr_db, o4) = snr_db;
+            *at(a.rate, o4) = rate;
+            *at(a.cap, o4) = cap;
         }
         if (a.write_table && !ABL(16)) {                                 // obs_fn.py:57-60
-            float2* t = reinterpret_cast<float2*>(a.table) + (row + (unsigned)i) * 3u;
+            float2* t = reinterpret_cast<float2*>(at(a.table, (row + (unsigned)i) * 24u));
             t[0] = make_float2(me.x, me.y);
             t[1] = rx;
             t[2] = make_float2(sinr_db, snr_db);
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const int lane = tid & 63;
         if (a.reward_fn == 2) {                                                          // reward_fn.py:52-57
 #pragma unroll
-            for (int u = 0; u < KEEP; ++u) { const int i = tid + u * TPE; a.reward[row + (unsigned)i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f; }
+            for (int u = 0; u < KEEP; ++u) { const int i = tid + u * TPE; *at(a.reward, (row + (unsigned)i) * 4u) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f; }
         }
         int ticket = 0;
         if (a.reward_fn == 1) {
@@ -597,7 +618,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const unsigned long long tot = *reinterpret_cast<volatile unsigned long long*>(s.red);
                 const float total = (float)tot * 2.3283064365386963e-10f;
                 const float r = *reinterpret_cast<volatile int*>(&s.flags[1]) ? -1.0f : total * a.inv_n;
-                for (int k = lane; k < N; k += 64) a.reward[row + (unsigned)k] = r;
+                for (int k = lane; k < N; k += 64) *at(a.reward, (row + (unsigned)k) * 4u) = r;
             }
             if (lane == 0) a.env_flags[b] = *reinterpret_cast<volatile int*>(&s.flags[0]);
         }
@@ -616,11 +637,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             float total = 0.0f;
             for (int w = 0; w < (TPE + 255) >> 8; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
             const float r = s.flags[1] ? -1.0f : total * a.inv_n;
-            FOR_MY_LINKS(u, i) a.reward[row + (unsigned)i] = r;
+            FOR_MY_LINKS(u, i) *at(a.reward, (row + (unsigned)i) * 4u) = r;
         }
     } else if (a.reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57
-        FOR_MY_LINKS(u, i) a.reward[row + (unsigned)i] = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
+        FOR_MY_LINKS(u, i) *at(a.reward, (row + (unsigned)i) * 4u) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
         __syncthreads();
     } else if (a.reward_fn == 3) {
         // CueSinrShannonRewardFunction, reward_fn.py:65-78
@@ -646,7 +667,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     bad |= (j != i) & ((s.aux[j] >> 24) != LINK_SIDELINK) & (__float_as_int(s.link[j].w) == rbi) &
                            (s.sinr[j] < a.reward_param);
             }
-            a.reward[row + (unsigned)i] = bad ? -1.0f : s.sh[i];
+            *at(a.reward, (row + (unsigned)i) * 4u) = bad ? -1.0f : s.sh[i];
         }
         __syncthreads();
     } else {
