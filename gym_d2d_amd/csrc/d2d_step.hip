@@ -207,18 +207,21 @@ struct LinkRaw {
     int act0, act1;      // raw action, or explicit (rb, pwr)
 };
 
-__device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, unsigned act_row, int i) {
+__device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, unsigned act_row, int i, int action_mode, int col_mode,
+                                             bool no_fixed = false) {
     LinkRaw in;
     in.act0 = 0; in.act1 = 0;
     // actions first, branch-free per lane (uniform branches only), so that no join forces a wait on the loads in flight
-    if (a.action_mode == 0) {
-        if (a.act_stride > 0) {
+    if (action_mode == 0) {
+        if (no_fixed) {
+            in.act0 = *at(a.actions, (act_row + (unsigned)i) * 4u);      // every link has its own column: column = link index
+        } else if (a.act_stride > 0) {
             // Fixed links are the first n_fixed links (the traffic-model case, CUE links first) or there are none: the
             // action column follows from the link index alone, so this load waits for nothing.  Arbitrary fixed sets
             // read their column from a host-built per-link array first (a second hop, but a uniform branch: no join
             // that would make the compiler wait for every load in flight).  A fixed link reads column 0 and ignores it.
             int col = i - a.n_fixed;
-            if (a.col_mode != 0) col = a.act_cols[i];
+            if (col_mode != 0) col = a.act_cols[i];
             in.act0 = *at(a.actions, (act_row + (unsigned)(col > 0 ? col : 0)) * 4u);
         }
     } else {
@@ -234,10 +237,11 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
 
 // (rb, tx power dBm) of a link: fixed by the traffic model (traffic_model.py:15-32), decoded from the raw action
 // (d2d_env.py:94-96, Python floor semantics; NB due_min_tx_power_dBm is not added back), or given explicitly.
-__device__ __forceinline__ void decode_link(const StepArgs& a, const LinkRaw& in, unsigned act_row, int& rb, int& p) {
-    if (in.ra.x & D2D_REC_FIXED_BIT) {
+__device__ __forceinline__ void decode_link(const StepArgs& a, const LinkRaw& in, unsigned act_row, int& rb, int& p, int action_mode,
+                                            bool no_fixed = false) {
+    if (!no_fixed && (in.ra.x & D2D_REC_FIXED_BIT)) {
         rb = in.ra.z; p = in.ra.w;            // no decode: any power is legal, as in the reference's Action(rb, pwr)
-    } else if (a.action_mode == 0) {
+    } else if (action_mode == 0) {
         const int act = in.act0;
         const int P = (int)(__float_as_uint(in.rc.w) & 0xFFFFu);
         const unsigned long long M = (unsigned long long)(unsigned)in.ra.z | ((unsigned long long)(unsigned)in.ra.w << 32);
@@ -298,9 +302,19 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
 #define STAMP(k) do { } while (0)
 #endif
 
-template <int MODE, int LPT, bool FULL>
+// HOT: the configuration a rollout runs in, with its uniform choices folded at compile time - raw agent actions for
+// every link (column = link index, no fixed links), SystemCapacity reward, compact table written, decoded (rb, pwr) exported,
+// nested walk, action prefetch on.  Twelve scalar compare-and-branch pairs and the code behind their other arms leave
+// the instruction stream (the kernel's SQ_WAIT_INST_ANY - waves waiting to be issued - is a quarter of its wave cycles).
+template <int MODE, int LPT, bool FULL, bool HOT = false>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr int KEEP = LPT > 0 ? LPT : 1;
+    const int cfg_action_mode = HOT ? 0 : a.action_mode;
+    const int cfg_col_mode = HOT ? 0 : a.col_mode;
+    const int cfg_reward_fn = HOT ? 1 : a.reward_fn;
+    const int cfg_write_table = HOT ? 1 : a.write_table;
+    const int cfg_walk = HOT ? 0 : a.walk;
+    const bool cfg_export_actions = HOT ? true : a.rb_out != nullptr;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int N = a.N, R = a.R, D = a.D, W = a.mask_words, TPE = a.tpe;
     const int tid = threadIdx.x;
@@ -327,10 +341,10 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) {
         const int i = lt + u * TPE;
-        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1);
+        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT);
     }
     // ---- pass 0: clear masks and flags
-    const bool want_masks = W > 0 && !ABL(4);
+    const bool want_masks = HOT || (W > 0 && !ABL(4));
     if (active) {
         if (want_masks) {
             // masks + sidelink words + summaries, 16 bytes per store (the region is 16-byte aligned and padded)
@@ -366,9 +380,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) me0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i);
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT);
         int rb, p;
-        decode_link(a, in, act_row, rb, p);
+        decode_link(a, in, act_row, rb, p, cfg_action_mode, HOT);
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(p) * in.rb_.x, __int_as_float(rb));
         s.link[i] = tuple;
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         s.aux[i] = in.ra.x & 0x0FFFFFFF;                                 // tx_dev | link_type << 24
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
-        if (a.rb_out && !ABL(32)) { *at(a.rb_out, (row + (unsigned)i) * 4u) = rb; *at(a.pwr_out, (row + (unsigned)i) * 4u) = p; }
+        if (cfg_export_actions && !ABL(32)) { *at(a.rb_out, (row + (unsigned)i) * 4u) = rb; *at(a.pwr_out, (row + (unsigned)i) * 4u) = p; }
         if (want_masks && !ABL(2)) {
             const unsigned bit = 1u << (i & 31);
             if ((unsigned)rb < (unsigned)R) {
@@ -403,13 +417,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // with four 512-thread workgroups per CU an HBM miss at the head of every workgroup is exposed four rounds deep
     // (+7 us at 4096 x 512: profiles/r2_action_prefetch.txt).  The value is consumed by a never-true test at the very end.
     int pf = 0;
-    if (a.prefetch_envs > 0 && a.action_mode == 0 && a.act_stride > 0) {
+    if (HOT || (a.prefetch_envs > 0 && cfg_action_mode == 0 && a.act_stride > 0)) {
         const int bq = b + a.prefetch_envs;
         const int bp = bq < a.B ? bq : a.B - 1;                         // clamped, not branched around (a join would wait)
 #pragma unroll
         for (int u = 0; u < KEEP; ++u) {
             const int i = lt + u * TPE;
-            const int col = i < a.act_stride ? i : a.act_stride - 1;
+            const int col = HOT || i < a.act_stride ? i : a.act_stride - 1;
             pf ^= *at(a.actions, ((unsigned)bp * (unsigned)a.act_stride + (unsigned)col) * 4u);
         }
     }
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     int my_flags = 0;
     bool violated = false;
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i);   // strided links: records re-read (L2)
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT);   // strided links: records re-read (L2)
         const float4 me = IN_REGS(u) ? me0[KEPT(u)] : s.link[i];
         const float2 rx = make_float2(in.pos.z, in.pos.w);
         const int rb = __float_as_int(me.w);
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             const int iw = i >> 5;
             const unsigned self = 1u << (i & 31);
             const unsigned* mrow = s.mask + rb;                          // word w of this RB: mrow[w * R]
-            if (a.walk == 1) {
+            if (cfg_walk == 1) {
                 // Flattened walk: a lane either fetches its next non-empty word or consumes one member; one loop
                 unsigned bits = 0u;
                 int jbase = 0;
@@ -552,7 +566,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             *at(a.rate, o4) = rate;
             *at(a.cap, o4) = cap;
         }
-        if (a.write_table && !ABL(16)) {                                 // obs_fn.py:57-60
+        if (cfg_write_table && !ABL(16)) {                                 // obs_fn.py:57-60
             float2* t = reinterpret_cast<float2*>(at(a.table, (row + (unsigned)i) * 24u));
             t[0] = make_float2(me.x, me.y);
             t[1] = rx;
@@ -565,8 +579,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             t[2] = make_float2(sinr_db, snr_db);
         }
         // staged only for the reward pass that reads them (reward_fn.py): 2 -> own sinr, sh; 3 -> sinr, sh
-        if (a.reward_fn >= 2) { s.sinr[i] = sinr_db; s.sh[i] = sh; }
-        if (a.reward_fn == 1) {
+        if (cfg_reward_fn >= 2) { s.sinr[i] = sinr_db; s.sh[i] = sh; }
+        if (cfg_reward_fn == 1) {
             // SystemCapacityRewardFunction's -1 rule (reward_fn.py:29-41), from this link's side: I am a non-D2D
             // link whose capacity is <= min_capacity and some D2D link shares my RB.  Masks / tuples of ALL links
             // were published by the barrier before this pass, so no further synchronisation is needed here.
@@ -592,17 +606,17 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     STAMP(6);
 
     // ---- pass 3: reward
-    if (FULL && a.reward_fn != 3) {
+    if (FULL && cfg_reward_fn != 3) {
         // No barrier: every wave publishes its part with LDS atomics, takes a ticket, and the wave that draws the last
         // ticket (all other waves' atomics precede their ticket in LDS order) finishes the env.  The capacity sum is
         // accumulated in 2^-32 Mbps fixed point, so the 64-bit integer total does not depend on arrival order.
         const int lane = tid & 63;
-        if (a.reward_fn == 2) {                                                          // reward_fn.py:52-57
+        if (cfg_reward_fn == 2) {                                                          // reward_fn.py:52-57
 #pragma unroll
             for (int u = 0; u < KEEP; ++u) { const int i = tid + u * TPE; *at(a.reward, (row + (unsigned)i) * 4u) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f; }
         }
         int ticket = 0;
-        if (a.reward_fn == 1) {
+        if (cfg_reward_fn == 1) {
             const float wsum = wave_sum(cap_part);
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), (unsigned long long)(wsum * 4294967296.0f));
             if (violated) atomicOr(&s.flags[1], 1);
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (lane == 0) ticket = atomicAdd(&s.flags[2], 1);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket == (TPE >> 6) - 1) {
-            if (a.reward_fn == 1) {
+            if (cfg_reward_fn == 1) {
                 // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone on a violation
                 const unsigned long long tot = *reinterpret_cast<volatile unsigned long long*>(s.red);
                 const float total = (float)tot * 2.3283064365386963e-10f;
@@ -625,7 +639,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         STAMP(7);
         return;
     }
-    if (a.reward_fn == 1) {
+    if (cfg_reward_fn == 1) {
         // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone if any link reported
         // a violation above.  One barrier: wave partial sums + the violation flag.
         const float wsum = wave_sum(cap_part);
@@ -639,11 +653,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             const float r = s.flags[1] ? -1.0f : total * a.inv_n;
             FOR_MY_LINKS(u, i) *at(a.reward, (row + (unsigned)i) * 4u) = r;
         }
-    } else if (a.reward_fn == 2) {
+    } else if (cfg_reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57
         FOR_MY_LINKS(u, i) *at(a.reward, (row + (unsigned)i) * 4u) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
         __syncthreads();
-    } else if (a.reward_fn == 3) {
+    } else if (cfg_reward_fn == 3) {
         // CueSinrShannonRewardFunction, reward_fn.py:65-78
         __syncthreads();
         FOR_MY_LINKS(u, i) {
@@ -784,19 +798,23 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     hipError_t err = hipSuccess;
     const int lpt = a.lpt;
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
-#define D2D_LAUNCH_1(M, S, F)                                                                            \
+    const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
+                     a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && a.ablate == 0 && a.dbg == nullptr &&
+                     a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
+#define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<M, S, F>),              \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<__VA_ARGS__>),          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         if (err == hipSuccess) {                                                                         \
-            hipLaunchKernelGGL((step_kernel<M, S, F>), grid, block, lds, stream, a);                     \
+            hipLaunchKernelGGL((step_kernel<__VA_ARGS__>), grid, block, lds, stream, a);                 \
             err = hipGetLastError();                                                                     \
         }                                                                                                \
     } while (0)
 #define D2D_LAUNCH(M)                                                                                    \
     do {                                                                                                 \
-        if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true);                                                  \
+        if (lpt == 1 && full && hot) D2D_LAUNCH_1(M, 1, true, true);                                     \
+        else if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true);                                             \
         else if (lpt == 2) D2D_LAUNCH_1(M, 2, false);                                                    \
         else if (lpt == 1 && full) D2D_LAUNCH_1(M, 1, true);                                             \
         else if (lpt == 1) D2D_LAUNCH_1(M, 1, false);                                                    \
