@@ -60,16 +60,18 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-// Sum over the 64 lanes, every lane receives the same bits: quad butterfly (xor 1, xor 2), half-row mirror, row mirror
-// (each lane adds its partner's partial: a + b == b + a), then the two cross-row steps.
+// Sum over the 64 lanes, returned wave-uniform: quad butterfly (xor 1, xor 2), half-row mirror, row mirror - every lane of a
+// 16-lane row then holds its row's sum (each lane adds its partner's partial: a + b == b + a) - then the gfx9 row
+// broadcasts (lane 15 of a row into the next row, lane 31 into rows 2-3) leave the total in lane 63, which is read with
+// v_readlane.  All DPP: no ds_bpermute round trip through the LDS crossbar (two of them before, > 100 cycles each).
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<0xB1>(v);          // quad_perm:[1,0,3,2]
     v += dpp_f32<0x4E>(v);          // quad_perm:[2,3,0,1]
     v += dpp_f32<0x141>(v);         // row_half_mirror
     v += dpp_f32<0x140>(v);         // row_mirror
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // (d^2)^(-e/2) for arbitrary exponent e, to ~3e-7 relative.  log2 of the mantissa and the integer exponent
