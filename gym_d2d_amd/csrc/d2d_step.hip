@@ -74,6 +74,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// v * 2^32 truncated to an integer, for 0 <= v < 2^32: whole part and fraction converted separately (two v_cvt_u32_f32)
+// instead of the generic float -> u64 sequence; the same value (the scaling by 2^32 is exact).
+__device__ __forceinline__ unsigned long long to_fixed_32_32(float v) {
+    const unsigned hi = (unsigned)v;
+    const float frac = v - (float)hi;
+    const unsigned lo = (unsigned)(frac * 4294967296.0f);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // (d^2)^(-e/2) for arbitrary exponent e, to ~3e-7 relative.  log2 of the mantissa and the integer exponent
 // are handled separately so the error does not scale with |log2(d^2)| (a plain exp2(h*log2(x)) loses ~2e-6).
 __device__ __forceinline__ float pow_neg_half(float d2, float e) {
@@ -389,7 +398,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(p) * in.rb_.x, __int_as_float(rb));
         s.link[i] = tuple;
         if (LPT == 0) s.rx[i] = make_float2(in.pos.z, in.pos.w);
-        s.aux[i] = in.ra.x & 0x0FFFFFFF;                                 // tx_dev | link_type << 24
+        if (!HOT) s.aux[i] = in.ra.x & 0x0FFFFFFF;                       // tx_dev | link_type << 24 (HOT: only the cold all-pairs
+                                                                         // route wants the type, and reads it from the record)
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
         if (cfg_export_actions && !ABL(32)) { *at(a.rb_out, (row + (unsigned)i) * 4u) = rb; *at(a.pwr_out, (row + (unsigned)i) * 4u) = p; }
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
-                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
+                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
                 if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                 acc = same ? fmaf(o.z, g, acc) : acc;
             }
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
-        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); dmin = min(dmin, __float_as_int(d2)); }
+        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
         float sig = me.z * g * rx_pl * rx_lin;                           // mW at the receiver, with rx gains
         float sig_snr = sig;
         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
@@ -593,7 +603,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         hit |= (s.mask[(unsigned)w * (unsigned)R + (unsigned)rb] & s.side[w]) != 0u;
                 } else {
                     for (int k = 0; k < N; ++k)
-                        hit |= (k != i) & ((s.aux[k] >> 24) == LINK_SIDELINK) & (__float_as_int(s.link[k].w) == rb);
+                        hit |= (k != i) & ((HOT ? (a.rec_a[k].x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK : s.aux[k] >> 24) == LINK_SIDELINK) &
+                               (__float_as_int(s.link[k].w) == rb);
                 }
                 violated |= hit;
             }
@@ -601,8 +612,17 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         cap_part += cap;
         // inverse-square gains: a zero distance in the walk shows up as 1/0 = inf in the accumulator (one test instead of a
         // min per interferer); the own link and the other path-loss modes track the smallest d2 itself
-        if (dmin == 0 || (MODE == PL_INV_SQUARE && !(acc <= 3.0e38f))) my_flags |= FLAG_ZERO_DISTANCE;
-        if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
+        if (MODE == PL_INV_SQUARE) {
+            // 1 / d^2 gains: a zero distance (own link: signal inf; an interferer: accumulator inf) always ends in a
+            // non-finite SINR, so the common case is one compare and the cause is sorted out behind it
+            if (!(fabsf(sinr_db) <= 3.0e38f)) {
+                my_flags |= FLAG_NON_FINITE;
+                if (d2 == 0.0f || !(acc <= 3.0e38f)) my_flags |= FLAG_ZERO_DISTANCE;
+            }
+        } else {
+            if (dmin == 0) my_flags |= FLAG_ZERO_DISTANCE;
+            if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
+        }
     }
     if (my_flags) atomicOr(&s.flags[0], my_flags);
     STAMP(6);
@@ -620,7 +640,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         int ticket = 0;
         if (cfg_reward_fn == 1) {
             const float wsum = wave_sum(cap_part);
-            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), (unsigned long long)(wsum * 4294967296.0f));
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), to_fixed_32_32(wsum));
             if (violated) atomicOr(&s.flags[1], 1);
         }
         // consume the prefetched word; tied to a value that exists only now, so the load is not waited for earlier
