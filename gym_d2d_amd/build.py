@@ -20,7 +20,10 @@ ARCH = 'gfx950'
 
 SOURCES = ['d2d_step.hip', 'd2d_obs.hip', 'd2d_reset.hip', 'd2d_capi.hip']
 HEADERS = [CSRC / 'd2d_internal.h', INCLUDE / 'd2d_hip.h']
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-unused-value']
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-unused-value',
+         # the kernels already issue their uniform-address LDS atomics from one lane (or on rare paths): LLVM's atomic optimizer
+         # only wraps them in mbcnt / readlane / popcount-multiply sequences
+         '-mllvm', '-amdgpu-atomic-optimizer-strategy=None']
 if os.environ.get('D2D_BUILD_DIAG') == '1':          # diagnostic build: the step kernel honours D2D_TUNE_STEP_ABLATE
     FLAGS.append('-DD2D_STEP_ABLATE=1')
 

@@ -199,11 +199,15 @@ __device__ __forceinline__ Smem carve(unsigned char* base, const StepLds& l, uns
 // base + 32-bit BYTE offset: selects to a global access with an SGPR base and ONE VGPR offset, so the 4-byte arrays of an env
 // share a single offset register and no 64-bit address is formed per array (10 v_lshl_add_u64 per link before).  The host
 // keeps B * N * 24 below 2^32 (run_step).
-// The offset is laundered through an empty asm so that its zero-extension happens next to the access: instruction
-// selection works per basic block, and a 64-bit offset pair carried in from another block is added with a v_lshl_add_u64.
+// The offset must be (re)defined in the basic block of the access - instruction selection works per block, and a 64-bit
+// offset pair carried in from another block is added with a v_lshl_add_u64 - so callers pass it through here once per block.
+__device__ __forceinline__ unsigned fresh(unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return byte_off;
+}
+
 template <class T>
 __device__ __forceinline__ T* at(T* base, unsigned byte_off) {
-    asm volatile("" : "+v"(byte_off));
     return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
 }
 
@@ -225,7 +229,7 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
     // actions first, branch-free per lane (uniform branches only), so that no join forces a wait on the loads in flight
     if (action_mode == 0) {
         if (no_fixed) {
-            in.act0 = *at(a.actions, (act_row + (unsigned)i) * 4u);      // every link has its own column: column = link index
+            in.act0 = *at(a.actions, fresh((act_row + (unsigned)i) * 4u));   // every link has its own column: column = link index
         } else if (a.act_stride > 0) {
             // Fixed links are the first n_fixed links (the traffic-model case, CUE links first) or there are none: the
             // action column follows from the link index alone, so this load waits for nothing.  Arbitrary fixed sets
@@ -233,16 +237,17 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
             // that would make the compiler wait for every load in flight).  A fixed link reads column 0 and ignores it.
             int col = i - a.n_fixed;
             if (col_mode != 0) col = a.act_cols[i];
-            in.act0 = *at(a.actions, (act_row + (unsigned)(col > 0 ? col : 0)) * 4u);
+            in.act0 = *at(a.actions, fresh((act_row + (unsigned)(col > 0 ? col : 0)) * 4u));
         }
     } else {
-        in.act0 = *at(a.rb_in, (row + (unsigned)i) * 4u);
-        in.act1 = *at(a.pwr_in, (row + (unsigned)i) * 4u);
+        const unsigned oe = fresh((row + (unsigned)i) * 4u);
+        in.act0 = *at(a.rb_in, oe);
+        in.act1 = *at(a.pwr_in, oe);
     }
     in.ra = a.rec_a[i];
     in.rb_ = a.rec_b[i];
     in.rc = a.rec_c[i];
-    in.pos = *at(a.lpos, (row + (unsigned)i) * 16u);
+    in.pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
     return in;
 }
 
@@ -371,8 +376,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 for (int k = lt; k < n16; k += TPE) m16[k] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        if (lt < 4) s.flags[lt] = 0;
-        if (lt < 16) s.red[lt] = 0.0f;
+        if (lt < 5) reinterpret_cast<uint4*>(s.red)[lt] = make_uint4(0u, 0u, 0u, 0u);   // red[16] + flags[4]: 80 bytes
     }
     // nothing that consumes a loaded value may be scheduled above this barrier: the wave would sit on the HBM round trip
     // before pass 0 instead of behind it
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                                                                          // route wants the type, and reads it from the record)
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
-        if (cfg_export_actions && !ABL(32)) { *at(a.rb_out, (row + (unsigned)i) * 4u) = rb; *at(a.pwr_out, (row + (unsigned)i) * 4u) = p; }
+        if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); *at(a.rb_out, oe) = rb; *at(a.pwr_out, oe) = p; }
         if (want_masks && !ABL(2)) {
             const unsigned bit = 1u << (i & 31);
             if ((unsigned)rb < (unsigned)R) {
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     STAMP(3);
     if (!ABL(64)) __syncthreads();
     STAMP(4);
-    const bool use_masks = want_masks && active && !(s.flags[0] & FLAG_RB_OOR);
+    const bool masks_on = want_masks && active;
     const bool skip_walk = ABL(7);
     if (ABL(512)) {                       // diagnostic: everything up to the end of pass 1
         if (me0[0].z == 1.2345f) a.env_flags[b] = 1;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         for (int u = 0; u < KEEP; ++u) {
             const int i = lt + u * TPE;
             const int col = HOT || i < a.act_stride ? i : a.act_stride - 1;
-            pf ^= *at(a.actions, ((unsigned)bp * (unsigned)a.act_stride + (unsigned)col) * 4u);
+            pf ^= *at(a.actions, fresh(((unsigned)bp * (unsigned)a.act_stride + (unsigned)col) * 4u));
         }
     }
 
@@ -452,6 +456,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float4 me = IN_REGS(u) ? me0[KEPT(u)] : s.link[i];
         const float2 rx = make_float2(in.pos.z, in.pos.w);
         const int rb = __float_as_int(me.w);
+        // a link whose own rb lies outside [0, R) has no mask row: it (and only it) takes the all-pairs sweep - links
+        // with an in-range rb never share it with such a link, so their mask walk is complete
+        const bool use_masks = masks_on && (unsigned)rb < (unsigned)R;
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const int txd = in.ra.x & D2D_REC_TXDEV_MASK, rxd = in.ra.y;
         const float rx_pl = in.rb_.y, rx_lin = in.rb_.z, noise = in.rb_.w;
@@ -565,26 +572,28 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float snr_db = 3.01029995663981195f * __builtin_amdgcn_logf(precise_div(sig_snr, noise));   // simulator.py:115
         // log2(1 + x) without losing small x: log2(u) * x / (u - 1), u = fl(1 + x)
         const float u1p = 1.0f + sinr_lin, um1 = u1p - 1.0f;
-        const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f
-                                     : __builtin_amdgcn_logf(u1p) * fast_div(sinr_lin, um1);
+        // both arms unconditional (the divisor is made harmless first), so the choice is a v_cndmask, not a divergent branch
+        const float sh_big = __builtin_amdgcn_logf(u1p) * fast_div(sinr_lin, um1 == 0.0f ? 1.0f : um1);
+        const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f : sh_big;
         const bool ok = sinr_db > sens;                                  // simulator.py:123,149
         const float rate = ok ? sh : 0.0f;
         const float cap = ok ? bw_mhz * sh : 0.0f;                       // simulator.py:150-151
 
         if (!ABL(8)) {
-            const unsigned o4 = (row + (unsigned)i) * 4u;
+            const unsigned o4 = fresh((row + (unsigned)i) * 4u);
             *at(a.sinr_db, o4) = sinr_db;
             *at(a.snr_db, o4) = snr_db;
             *at(a.rate, o4) = rate;
             *at(a.cap, o4) = cap;
         }
         if (cfg_write_table && !ABL(16)) {                                 // obs_fn.py:57-60
-            float2* t = reinterpret_cast<float2*>(at(a.table, (row + (unsigned)i) * 24u));
+            const unsigned o4t = fresh((row + (unsigned)i) * 4u);
+            float2* t = reinterpret_cast<float2*>(at(a.table, (o4t << 2) + (o4t << 1)));      // 24 bytes per link, no v_mul_lo
             t[0] = make_float2(me.x, me.y);
             t[1] = rx;
             t[2] = make_float2(sinr_db, snr_db);
         }
-        if (a.fuse_obs) {
+        if (!FULL && a.fuse_obs) {
             float2* t = reinterpret_cast<float2*>(s.tflat + 6 * i);
             t[0] = make_float2(me.x, me.y);
             t[1] = rx;
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const int lane = tid & 63;
         if (cfg_reward_fn == 2) {                                                          // reward_fn.py:52-57
 #pragma unroll
-            for (int u = 0; u < KEEP; ++u) { const int i = tid + u * TPE; *at(a.reward, (row + (unsigned)i) * 4u) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f; }
+            for (int u = 0; u < KEEP; ++u) { const int i = tid + u * TPE; *at(a.reward, fresh((row + (unsigned)i) * 4u)) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f; }
         }
         int ticket = 0;
         if (cfg_reward_fn == 1) {
@@ -651,12 +660,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (ticket == (TPE >> 6) - 1) {
             if (cfg_reward_fn == 1) {
                 // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone on a violation
-                const unsigned long long tot = *reinterpret_cast<volatile unsigned long long*>(s.red);
+                const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long*>(s.red), 0ull);   // LDS read that cannot be hoisted
                 const float total = (float)tot * 2.3283064365386963e-10f;
-                const float r = *reinterpret_cast<volatile int*>(&s.flags[1]) ? -1.0f : total * a.inv_n;
-                for (int k = lane; k < N; k += 64) *at(a.reward, (row + (unsigned)k) * 4u) = r;
+                const float r = atomicOr(&s.flags[1], 0) ? -1.0f : total * a.inv_n;
+                for (int k = lane; k < N; k += 64) *at(a.reward, fresh((row + (unsigned)k) * 4u)) = r;
             }
-            if (lane == 0) a.env_flags[b] = *reinterpret_cast<volatile int*>(&s.flags[0]);
+            if (lane == 0) a.env_flags[b] = atomicOr(&s.flags[0], 0);
         }
         STAMP(7);
         return;
@@ -673,11 +682,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             float total = 0.0f;
             for (int w = 0; w < (TPE + 255) >> 8; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
             const float r = s.flags[1] ? -1.0f : total * a.inv_n;
-            FOR_MY_LINKS(u, i) *at(a.reward, (row + (unsigned)i) * 4u) = r;
+            FOR_MY_LINKS(u, i) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = r;
         }
     } else if (cfg_reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57
-        FOR_MY_LINKS(u, i) *at(a.reward, (row + (unsigned)i) * 4u) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
+        FOR_MY_LINKS(u, i) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = s.sinr[i] >= a.reward_param ? s.sh[i] : -1.0f;
         __syncthreads();
     } else if (cfg_reward_fn == 3) {
         // CueSinrShannonRewardFunction, reward_fn.py:65-78
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         FOR_MY_LINKS(u, i) {
             const int rbi = IN_REGS(u) ? __float_as_int(me0[KEPT(u)].w) : __float_as_int(s.link[i].w);
             bool bad = false;
-            if (use_masks) {
+            if (masks_on && (unsigned)rbi < (unsigned)R) {
                 unsigned live = s.summ[rbi];
                 while (live) {
                     const int w = __builtin_ctz(live);
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     bad |= (j != i) & ((s.aux[j] >> 24) != LINK_SIDELINK) & (__float_as_int(s.link[j].w) == rbi) &
                            (s.sinr[j] < a.reward_param);
             }
-            *at(a.reward, (row + (unsigned)i) * 4u) = bad ? -1.0f : s.sh[i];
+            *at(a.reward, fresh((row + (unsigned)i) * 4u)) = bad ? -1.0f : s.sh[i];
         }
         __syncthreads();
     } else {
