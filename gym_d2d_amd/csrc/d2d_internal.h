@@ -50,6 +50,7 @@ struct StepArgs {
     int reward_fn;
     float reward_param;
     int write_table;
+    int all_magic;           // every non-fixed link's power alphabet has a division magic (P < 512): the HOT kernel skips the test
     int ablate;              // DIAGNOSTIC builds only (-DD2D_STEP_ABLATE=1): skip parts of the kernel to time the rest
     unsigned long long* dbg; // DIAGNOSTIC builds only: [workgroup][wave][8] shader-clock stamps at the phase boundaries, or null
     // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)

@@ -262,7 +262,7 @@ __device__ __forceinline__ void decode_link(const StepArgs& a, const LinkRaw& in
         const int P = (int)(__float_as_uint(in.rc.w) & 0xFFFFu);
         const unsigned long long M = (unsigned long long)(unsigned)in.ra.z | ((unsigned long long)(unsigned)in.ra.w << 32);
         int q, r;
-        if (act >= 0 && M != 0ull) {
+        if (act >= 0 && (no_fixed || M != 0ull)) {       // no_fixed = the HOT kernel: the host checked that every link has a magic
             // exact for 0 <= act < 2^31 and P < 2^9: q = floor(act * ceil(2^40 / P) / 2^40) (host-computed magic)
             q = (int)(((unsigned long long)(unsigned)act * M) >> 40);
             r = act - q * P;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // action row of the env that the workgroup `prefetch_envs` later will own - a multiple of 8, so it lands in the L2 of
     // the XCD that will read it (round-robin dispatch).  Fresh actions are the one input that is never cache resident, and
     // with four 512-thread workgroups per CU an HBM miss at the head of every workgroup is exposed four rounds deep
-    // (+7 us at 4096 x 512: profiles/r2_action_prefetch.txt).  The value is consumed by a never-true test at the very end.
+    // (+7 us at 4096 x 512: profiles/r2_action_prefetch.txt).  The value is consumed by an empty asm at the very end.
     int pf = 0;
     if (HOT || (a.prefetch_envs > 0 && cfg_action_mode == 0 && a.act_stride > 0)) {
         const int bq = b + a.prefetch_envs;
@@ -652,9 +652,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), to_fixed_32_32(wsum));
             if (violated) atomicOr(&s.flags[1], 1);
         }
-        // consume the prefetched word; tied to a value that exists only now, so the load is not waited for earlier
-        // (flags[3] is scratch: the test's outcome changes nothing)
-        if (pf == (__float_as_int(cap_part) | (int)0x80000000)) atomicOr(&s.flags[3], 1);
+        // consume the prefetched word here, at the end: an empty asm that names the register keeps the load alive and costs
+        // no instruction (the wait for it lands here, long after it has arrived)
+        asm volatile("" ::"v"(pf));
         if (lane == 0) ticket = atomicAdd(&s.flags[2], 1);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket == (TPE >> 6) - 1) {
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         __syncthreads();
     }
 
-    if (pf == (__float_as_int(cap_part) | (int)0x80000000)) atomicOr(&s.flags[3], 1);   // consume the prefetched word (late)
+    asm volatile("" ::"v"(pf));                    // consume the prefetched word (late)
     if (active && lt == 0) a.env_flags[b] = s.flags[0];
 
     // ---- pass 4 (small N only): LinearObs expansion of this workgroup's envs, obs_fn.py:43-53.  Every thread of the
@@ -831,7 +831,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
                      a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && a.ablate == 0 && a.dbg == nullptr &&
-                     a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
+                     a.mask_words > 0 && a.all_magic && (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
