@@ -262,7 +262,7 @@ __device__ __forceinline__ void decode_link(const StepArgs& a, const LinkRaw& in
         const int P = (int)(__float_as_uint(in.rc.w) & 0xFFFFu);
         const unsigned long long M = (unsigned long long)(unsigned)in.ra.z | ((unsigned long long)(unsigned)in.ra.w << 32);
         int q, r;
-        if (act >= 0 && (no_fixed || M != 0ull)) {       // no_fixed = the HOT kernel: the host checked that every link has a magic
+        if (__builtin_expect(act >= 0 && (no_fixed || M != 0ull), 1)) {       // no_fixed = the HOT kernel: the host checked that every link has a magic
             // exact for 0 <= act < 2^31 and P < 2^9: q = floor(act * ceil(2^40 / P) / 2^40) (host-computed magic)
             q = (int)(((unsigned long long)(unsigned)act * M) >> 40);
             r = act - q * P;
@@ -310,6 +310,9 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
 #define D2D_STEP_ABLATE 0       /* diagnostic build: honour StepArgs::ablate (tools/ab_step.py ablate) */
 #endif
 #define ABL(bit) (D2D_STEP_ABLATE && (a.ablate & (bit)))
+// branch weights: block placement moves the rare arms (invalid actions, all-pairs sweep, flag reporting) behind the hot path
+#define LIKELY(x) __builtin_expect(!!(x), 1)
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)
 // diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py)
 #if D2D_STEP_ABLATE
 #define STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0)                                                              \
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); *at(a.rb_out, oe) = rb; *at(a.pwr_out, oe) = p; }
         if (want_masks && !ABL(2)) {
             const unsigned bit = 1u << (i & 31);
-            if ((unsigned)rb < (unsigned)R) {
+            if (LIKELY((unsigned)rb < (unsigned)R)) {
                 atomicOr(&s.mask[__umul24((unsigned)(i >> 5), (unsigned)R) + (unsigned)rb], bit);
                 atomicOr(&s.summ[rb], 1u << (i >> 5));
             }
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         int dmin = 0x7F000000;                                           // bits of the smallest squared distance met (d2 >= 0:
                                                                          // integer order == float order); 0 <=> 'math domain error'
         if (skip_walk) {
-        } else if (use_masks) {
+        } else if (LIKELY(use_masks)) {
             unsigned live = s.summ[rb];                                  // non-empty words of this RB, ascending
             const int iw = i >> 5;
             const unsigned self = 1u << (i & 31);
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             // SystemCapacityRewardFunction's -1 rule (reward_fn.py:29-41), from this link's side: I am a non-D2D
             // link whose capacity is <= min_capacity and some D2D link shares my RB.  Masks / tuples of ALL links
             // were published by the barrier before this pass, so no further synchronisation is needed here.
-            if (type != LINK_SIDELINK && cap <= a.reward_param) {
+            if (UNLIKELY(type != LINK_SIDELINK && cap <= a.reward_param)) {
                 bool hit = false;
                 if (use_masks) {
                     for (int w = 0; w < W; ++w)
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (MODE == PL_INV_SQUARE) {
             // 1 / d^2 gains: a zero distance (own link: signal inf; an interferer: accumulator inf) always ends in a
             // non-finite SINR, so the common case is one compare and the cause is sorted out behind it
-            if (!(fabsf(sinr_db) <= 3.0e38f)) {
+            if (UNLIKELY(!(fabsf(sinr_db) <= 3.0e38f))) {
                 my_flags |= FLAG_NON_FINITE;
                 if (d2 == 0.0f || !(acc <= 3.0e38f)) my_flags |= FLAG_ZERO_DISTANCE;
             }
@@ -830,7 +833,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const int lpt = a.lpt;
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
-                     a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && a.ablate == 0 && a.dbg == nullptr &&
+                     a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && (a.ablate == 0 || a.ablate == 8192) &&
                      a.mask_words > 0 && a.all_magic && (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
