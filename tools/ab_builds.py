@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Same-box A/B of library BUILDS (box-to-box spread on the pool is +-5 %, more than most kernel changes are worth).
+
+    python tools/ab_builds.py prepare <commit|WORKTREE> ...     # here (no GPU): build each into tools/ab_libs/<name>.so
+    python tools/ab_builds.py run [--workload stress|default] [--passes 2]      # on the GPU box: alternate processes, one per build
+
+`prepare` uses git worktrees for commits and the working tree's own build for WORKTREE; the .so files are git-ignored but
+travel with the gpurun snapshot.  `run` times each build in its own process (the library path is patched before the
+first load), alternating builds so that drift hits all of them alike, and prints one JSON line per (pass, build).
+"""
+import argparse
+import json
+import shutil
+import statistics
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+LIBS = ROOT / 'tools' / 'ab_libs'
+
+
+def prepare(names):
+    LIBS.mkdir(exist_ok=True)
+    for old in LIBS.glob('*.so'):
+        old.unlink()
+    for k, name in enumerate(names):
+        out = LIBS / f'{k:02d}_{name.replace("/", "_")}.so'
+        if name == 'WORKTREE':
+            subprocess.run([sys.executable, '-m', 'gym_d2d_amd.build', '--force'], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+            shutil.copy(ROOT / 'gym_d2d_amd' / 'lib' / 'libd2d_hip.so', out)
+        else:
+            wt = Path('/tmp') / f'ab_wt_{k}'
+            subprocess.run(['git', 'worktree', 'remove', '--force', str(wt)], cwd=ROOT, stderr=subprocess.DEVNULL)
+            subprocess.run(['git', 'worktree', 'add', '-q', str(wt), name], cwd=ROOT, check=True)
+            subprocess.run([sys.executable, '-m', 'gym_d2d_amd.build', '--force'], cwd=wt, check=True, stdout=subprocess.DEVNULL)
+            shutil.copy(wt / 'gym_d2d_amd' / 'lib' / 'libd2d_hip.so', out)
+            subprocess.run(['git', 'worktree', 'remove', '--force', str(wt)], cwd=ROOT)
+        print('built', out.name)
+
+
+def one(lib, workload):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools'))
+    from gym_d2d_amd import _native
+    _native.LIB_PATH = Path(lib).resolve()
+    import torch
+    from ab_step import timed
+    from gym_d2d_amd.envs import VecD2DEnv
+    from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
+    if workload == 'stress':
+        b, c, p, r = 4096, 256, 256, 256
+        env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
+        cols = c + p
+    else:
+        b, c, p, r = 1024, 25, 25, 25
+        env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': LinearObsFunction}, num_envs=b, cue_actions='traffic')
+        cols = p
+    env.reset(seed=1)
+    h = env.simulator.handle
+    act = torch.randint(0, r * 21, (64, b, cols), device=env.device, dtype=torch.int32)
+    t = [timed(h, act, 32) for _ in range(15)]
+    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
+
+
+def run(workload, passes):
+    for k in range(passes):
+        for lib in sorted(LIBS.glob('*.so')):
+            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload], capture_output=True, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            print(line[-1] if line else f'{lib.name}: failed {r.stderr[-300:]}', flush=True)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('what', choices=['prepare', 'run', 'one'])
+    ap.add_argument('names', nargs='*')
+    ap.add_argument('--workload', default='stress')
+    ap.add_argument('--passes', type=int, default=2)
+    a = ap.parse_args()
+    if a.what == 'prepare':
+        prepare(a.names)
+    elif a.what == 'run':
+        run(a.workload, a.passes)
+    else:
+        one(a.names[0], a.workload)
