@@ -74,7 +74,6 @@ struct d2d_handle {
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
     bool lpos_dirty = true;
     unsigned long long* dbg = nullptr;   // diagnostic builds only
-    bool all_magic = false;         // every non-fixed link decodes with the multiply-shift (power alphabet < 512 levels)
     bool std_layout = false;        // link i < C is (cue i -> mbs), link C + k is (due 2k -> due 2k+1): d2d_reset_positions writes lpos itself
     float* gain_table = nullptr;
     size_t gain_elems = 0;
@@ -175,18 +174,19 @@ int refresh_tables(d2d_handle* h) {
     const int levels[4] = {0, h->cfg.pwr_levels_cue, h->cfg.pwr_levels_mbs, h->cfg.pwr_levels_due};   // by d2d_link_type
     int col = 0;
     bool prefix = true;               // are the fixed links exactly the first n_fixed links?
-    bool all_magic = true;
     for (int i = 0; i < N; ++i) {
         const int t = h->host_tx[i], r = h->host_rx[i];
         const bool fixed = h->fixed_rb[i] != INT32_MIN;
         ra[4 * i + 0] = t | (h->host_type[i] << D2D_REC_TYPE_SHIFT) | (fixed ? D2D_REC_FIXED_BIT : 0);
         ra[4 * i + 1] = r;
         const uint32_t P = (uint32_t)levels[h->host_type[i]];
-        const uint64_t M = P < 512 ? ((1ull << 40) + P - 1) / P : 0ull;       // ceil(2^40 / P); 0 -> hardware divide
-        ra[4 * i + 2] = fixed ? h->fixed_rb[i] : (int32_t)(uint32_t)(M & 0xFFFFFFFFull);
-        ra[4 * i + 3] = fixed ? h->fixed_pwr[i] : (int32_t)(uint32_t)(M >> 32);
+        // action decode by multiply-high: M = ceil(2^32 / P) is exact for act < 2^32 / P (error term M P - 2^32 < P); the
+        // bound travels with it, capped at 2^24 - 1 (q * P then fits the 24-bit multiplier).  P < 2: hardware divide.
+        const uint32_t M = P >= 2 ? (uint32_t)(((1ull << 32) + P - 1) / P) : 0u;
+        const uint32_t lim = P >= 2 ? (uint32_t)std::min<uint64_t>(0xFFFFFFFFull / P, (1u << 24) - 1) : 0u;
+        ra[4 * i + 2] = fixed ? h->fixed_rb[i] : (int32_t)M;
+        ra[4 * i + 3] = fixed ? h->fixed_pwr[i] : (int32_t)lim;
         if (fixed != (i < h->n_fixed)) prefix = false;
-        if (!fixed && M == 0ull) all_magic = false;
         const uint32_t packed = (P & 0xFFFFu) | ((uint32_t)(fixed ? 0 : col++) << 16);
         std::memcpy(&rc[4 * i + 3], &packed, 4);
         rb[4 * i + 0] = cols[0 * D + t];    // tx_lin
@@ -207,7 +207,6 @@ int refresh_tables(d2d_handle* h) {
     HIP_TRY(hipMemcpyAsync(h->rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // rec is a stack-lifetime host buffer
     h->col_mode = prefix ? 0 : 1;
-    h->all_magic = all_magic;
     const int C = h->cfg.num_cues;
     bool std_layout = N == C + (D - 1 - C) / 2 && D == 1 + C + 2 * (N - C);
     for (int i = 0; i < N && std_layout; ++i)
@@ -325,7 +324,6 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         return fail(D2D_ERR_UNSUPPORTED, "envs x links per GPU must stay below 2^32 / 24 (32-bit byte offsets in the step kernel)");
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
-    s.all_magic = h->all_magic ? 1 : 0;
     s.ablate = h->tune_step_ablate;
     s.dbg = nullptr;
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE

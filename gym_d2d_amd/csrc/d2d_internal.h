@@ -16,7 +16,7 @@ enum PlMode : int {
 // Per-link record, three 16-byte rows shared by all envs and read coalesced by link index (L2-resident).  Built on
 // the host from the per-device columns + the link table whenever links, tables or fixed actions change.
 //   a (int4)   x: tx device | link_type << 24 | fixed << 28     y: rx device
-//              z, w: fixed ? (rb, tx power dBm) : (low, high word of the division magic ceil(2^40 / P), 0 = divide)
+//              z, w: fixed ? (rb, tx power dBm) : (division magic ceil(2^32 / P), largest action it is exact for; 0, 0 = divide)
 //   b (float4) x: tx_lin = 10^((eirp_off - a_tx)/10)   y: rx_pl = 10^(-a_rx/10)   z: rx_lin = 10^(rx_off/10)
 //              w: noise_mw = 10^(thermal_noise_dBm/10)
 //   c (float4) x: rx_sensitivity_dBm   y: 1e-6 * RB bandwidth (Hz) of the tx   z: path-loss exponent of the tx
@@ -50,7 +50,6 @@ struct StepArgs {
     int reward_fn;
     float reward_param;
     int write_table;
-    int all_magic;           // every non-fixed link's power alphabet has a division magic (P < 512): the HOT kernel skips the test
     int ablate;              // DIAGNOSTIC builds only (-DD2D_STEP_ABLATE=1): skip parts of the kernel to time the rest
     unsigned long long* dbg; // DIAGNOSTIC builds only: [workgroup][wave][8] shader-clock stamps at the phase boundaries, or null
     // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)

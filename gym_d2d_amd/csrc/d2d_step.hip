@@ -260,12 +260,14 @@ __device__ __forceinline__ void decode_link(const StepArgs& a, const LinkRaw& in
     } else if (action_mode == 0) {
         const int act = in.act0;
         const int P = (int)(__float_as_uint(in.rc.w) & 0xFFFFu);
-        const unsigned long long M = (unsigned long long)(unsigned)in.ra.z | ((unsigned long long)(unsigned)in.ra.w << 32);
         int q, r;
-        if (__builtin_expect(act >= 0 && (no_fixed || M != 0ull), 1)) {       // no_fixed = the HOT kernel: the host checked that every link has a magic
-            // exact for 0 <= act < 2^31 and P < 2^9: q = floor(act * ceil(2^40 / P) / 2^40) (host-computed magic)
-            q = (int)(((unsigned long long)(unsigned)act * M) >> 40);
-            r = act - q * P;
+        if (__builtin_expect((unsigned)act <= (unsigned)in.ra.w, 1)) {
+            // q = floor(act * M / 2^32), M = ceil(2^32 / P): exact while act * (M P - 2^32) < 2^32, i.e. for act < 2^32 / P;
+            // the host stores the bound (capped at 2^24 - 1 so that q * P is a 24-bit multiply) next to M.  One
+            // v_mul_hi_u32; a negative action is a huge unsigned and takes the other arm, as does a link without a magic
+            // (bound 0: only act == 0 passes, and M = 0 decodes it correctly)
+            q = (int)__umulhi((unsigned)act, (unsigned)in.ra.z);
+            r = act - (int)__umul24((unsigned)q, (unsigned)P);
         } else {
             q = act / P; r = act - q * P;
             if (r < 0) { r += P; q -= 1; }
@@ -507,11 +509,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 if (live) {
                     int w = __builtin_ctz(live);
                     live &= live - 1u;
-                    unsigned bits = mrow[__umul24((unsigned)w, (unsigned)R)];
+                    const unsigned R4 = (unsigned)R * 4u;               // byte pitch of a mask word row: address = one v_mad_u32_u24
+                    const unsigned char* mrow_b = reinterpret_cast<const unsigned char*>(mrow);
+                    unsigned bits = *reinterpret_cast<const unsigned*>(mrow_b + __umul24((unsigned)w, R4));
                     while (true) {
                         const bool more = live != 0u;
                         const int wn = more ? __builtin_ctz(live) : w;
-                        const unsigned bits_n = mrow[__umul24((unsigned)wn, (unsigned)R)];   // prefetch (a re-read when !more)
+                        const unsigned bits_n = *reinterpret_cast<const unsigned*>(mrow_b + __umul24((unsigned)wn, R4));   // prefetch (a re-read when !more)
                         if (w == iw) bits &= ~self;                      // .difference({action}), simulator.py:95
                         while (bits) {
                             const int j = (w << 5) + __builtin_ctz(bits);
@@ -834,7 +838,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
                      a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && (a.ablate == 0 || a.ablate == 8192) &&
-                     a.mask_words > 0 && a.all_magic && (mode == PL_INV_SQUARE || mode == PL_POWER);
+                     a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \

@@ -438,3 +438,27 @@ def test_reset_writes_the_link_position_rows_itself_for_the_standard_link_list(n
     assert np.array_equal(t[:, :, 0], px[:, tx]) and np.array_equal(t[:, :, 1], py[:, tx])
     assert np.array_equal(t[:, :, 2], px[:, rx]) and np.array_equal(t[:, :, 3], py[:, rx])
     env.close()
+
+
+def test_action_decode_is_exact_for_every_magnitude(native):
+    """rb = a // P, pwr = a % P by one multiply-high below the bound stored with the magic, by division above it and for
+    negatives (Python floor semantics): checked at the bound's edges, at 2^24, near 2^31 and below zero, for the CUE (24
+    levels) and DUE (21 levels) alphabets."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    from gym_d2d_amd.envs.obs_fn import OwnLinkObsFunction
+    C, P, R = 64, 64, 8                                            # N = 128: the one-env-per-workgroup kernels
+    env = VecD2DEnv({'num_rbs': R, 'num_cues': C, 'num_due_pairs': P, 'obs_fn': OwnLinkObsFunction}, num_envs=3)
+    env.reset(seed=3)
+    edge = [0, 1, 20, 21, 23, 24, R * 21 - 1, R * 24 - 1, 65535, 65536, (1 << 24) - 2, (1 << 24) - 1, 1 << 24, (1 << 24) + 1,
+            (1 << 24) + 23, 178956970, 178956971, 204522252, 204522253, (1 << 31) - 1, (1 << 31) - 24, -1, -2, -21, -24, -25,
+            -(1 << 24), -(1 << 31) + 1]
+    rng = np.random.default_rng(0)
+    acts = rng.choice(edge, size=(3, C + P)).astype(np.int64)
+    acts[0, :len(edge)] = edge; acts[1, C:C + len(edge)] = edge
+    _, _, _, info = env.step(torch.as_tensor(acts.astype(np.int32), device=env.device))
+    torch.cuda.synchronize()
+    levels = np.array([24] * C + [21] * P)
+    assert np.array_equal(info['rb'].cpu().numpy(), acts // levels[None, :])
+    assert np.array_equal(info['tx_pwr_dbm'].cpu().numpy(), acts % levels[None, :])
+    env.close()
