@@ -559,6 +559,28 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             for (int k = 0; k < 32; ++k) { x0 = fmaf(x0, 1.0001f, 0.5f); x1 = fmaf(x1, 0.9999f, 0.25f); }
             if (x0 + x1 == 1.2345f) my_flags |= 1 << 29;
         }
+        if (ABL(32768)) {                    // diagnostic: 64 extra SALU instructions per wave (wave-uniform integer chain)
+            int sx = __builtin_amdgcn_readfirstlane(rb);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { sx = sx * 3 + k; sx ^= sx >> 3; asm volatile("" : "+s"(sx)); }
+            if (sx == 0x12345678) my_flags |= 1 << 28;
+        }
+        if (ABL(65536)) {                    // diagnostic: 8 extra random 16-byte LDS reads per lane (the walk's tuple reads)
+            float lx = 0.0f;
+            unsigned jj = (unsigned)i;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { jj = (jj * 73u + 19u) & (unsigned)(N - 1); const float4 o = s.link[jj]; lx += o.x; }
+            if (lx == 1.2345f) my_flags |= 1 << 27;
+        }
+        if (ABL(131072)) {                   // diagnostic: 8 extra LDS atomics per lane on random mask words
+            unsigned jj = (unsigned)i;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { jj = (jj * 73u + 19u) & 1023u; atomicOr(&s.mask[jj], 0u); }
+        }
+        if (ABL(262144)) {                   // diagnostic: 4 extra 4-byte global stores per lane (into this link's own result slots)
+            const unsigned o4x = fresh((row + (unsigned)i) * 4u);
+            *at(a.rate, o4x) = 0.0f; *at(a.cap, o4x) = 0.0f; *at(a.snr_db, o4x) = 0.0f; *at(a.sinr_db, o4x) = 0.0f;
+        }
         // own link: simulator.py:93
         const float dx = me.x - rx.x, dy = me.y - rx.y;
         const float d2 = fmaf(dx, dx, dy * dy);
@@ -837,7 +859,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const int lpt = a.lpt;
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
-                     a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && (a.ablate == 0 || a.ablate == 8192) &&
+                     a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
