@@ -71,6 +71,7 @@ struct d2d_handle {
     // device-side tables
     float4* rec = nullptr;          // per-link records: 3 rows of Nmax x 16 B (d2d_internal.h), see refresh_tables
     int* act_cols = nullptr;        // [Nmax] action column per link (arbitrary fixed sets)
+    unsigned* side_words = nullptr; // [ceil(Nmax / 32)] sidelink membership bits, rebuilt with the records
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
     bool lpos_dirty = true;
     unsigned long long* dbg = nullptr;   // diagnostic builds only
@@ -203,6 +204,10 @@ int refresh_tables(d2d_handle* h) {
         std::memcpy(&packed, &rc[4 * i + 3], 4);
         cols_host[i] = (int32_t)(packed >> 16);
     }
+    std::vector<uint32_t> side_host((size_t)(S + 31) / 32 + 1, 0u);
+    for (int i = 0; i < N; ++i)
+        if (h->host_type[i] == D2D_SIDELINK) side_host[i >> 5] |= 1u << (i & 31);
+    HIP_TRY(hipMemcpyAsync(h->side_words, side_host.data(), side_host.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->act_cols, cols_host.data(), cols_host.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // rec is a stack-lifetime host buffer
@@ -442,6 +447,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.rec_c = h->rec + 2 * (size_t)S;
     s.lpos = h->lpos;
     s.act_cols = h->act_cols;
+    s.side_words = h->side_words;
     s.gain_table = h->gain_table;
     s.table_env_stride = h->table_per_env ? (long long)D * D : 0;
     s.env_offset = h->env_offset;
@@ -558,6 +564,7 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     CREATE_TRY(hipMalloc(&h->rec, (size_t)3 * h->Nmax * 16));
     CREATE_TRY(hipMalloc(&h->lpos, (size_t)h->B * h->Nmax * 16));
     CREATE_TRY(hipMalloc(&h->act_cols, (size_t)h->Nmax * 4));
+    CREATE_TRY(hipMalloc(&h->side_words, ((size_t)(h->Nmax + 31) / 32 + 1) * 4));
     CREATE_TRY(hipMalloc(&h->status, 4));
     CREATE_TRY(hipMemset(h->status, 0, 4));
 #undef CREATE_TRY
@@ -577,6 +584,7 @@ int d2d_destroy(d2d_handle* h) {
     if (h->lpos) hipFree(h->lpos);
     if (h->dbg) hipFree(h->dbg);
     if (h->act_cols) hipFree(h->act_cols);
+    if (h->side_words) hipFree(h->side_words);
     if (h->host_out_dev) hipFree(h->host_out_dev);
     if (h->host_out_pinned) hipHostFree(h->host_out_pinned);
     if (h->host_in_dev) hipFree(h->host_in_dev);

@@ -64,6 +64,7 @@ struct StepArgs {
     const float4* rec_b;     // [N]
     const float4* rec_c;     // [N]
     const int* act_cols;     // [N] action column of every link (col_mode 1 only; 0 for fixed links)
+    const unsigned* side_words;  // [ceil(N / 32)] bit i set <=> link i is a sidelink (host-built with the records)
     const float4* lpos;      // [B, N] (tx_x, tx_y, rx_x, rx_y) of every link, rebuilt when positions / links change
     const float* gain_table; // PL_TABLE: linear gain [D,D] (tx major)
     long long table_env_stride; // 0 or D*D

@@ -419,7 +419,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 atomicOr(&s.summ[rb], 1u << (i >> 5));
             }
             else atomicOr(&s.flags[0], FLAG_RB_OOR);
-            if (type == LINK_SIDELINK) atomicOr(&s.side[i >> 5], bit);
+            // sidelink membership words are a property of the link list: built on the host (StepArgs::side_words).  Only
+            // CueSinrShannon reads them in its hot loop and wants them in LDS; SystemCapacity's -1 rule reads the global copy
+            if (cfg_reward_fn == 3 && (i & 31) == 0) s.side[i >> 5] = a.side_words[i >> 5];
         }
     }
     STAMP(3);
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 bool hit = false;
                 if (use_masks) {
                     for (int w = 0; w < W; ++w)
-                        hit |= (s.mask[(unsigned)w * (unsigned)R + (unsigned)rb] & s.side[w]) != 0u;
+                        hit |= (s.mask[(unsigned)w * (unsigned)R + (unsigned)rb] & a.side_words[w]) != 0u;
                 } else {
                     for (int k = 0; k < N; ++k)
                         hit |= (k != i) & ((HOT ? (a.rec_a[k].x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK : s.aux[k] >> 24) == LINK_SIDELINK) &
