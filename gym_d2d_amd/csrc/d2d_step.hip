@@ -323,11 +323,12 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
 #define STAMP(k) do { } while (0)
 #endif
 
-// HOT: the configuration a rollout runs in, with its uniform choices folded at compile time - raw agent actions for
+// HOT: the configuration a rollout runs in, with its uniform choices folded at compile time.  Level 1 - raw agent actions for
 // every link (column = link index, no fixed links), SystemCapacity reward, compact table written, decoded (rb, pwr) exported,
-// nested walk, action prefetch on.  Twelve scalar compare-and-branch pairs and the code behind their other arms leave
-// the instruction stream (the kernel's SQ_WAIT_INST_ANY - waves waiting to be issued - is a quarter of its wave cycles).
-template <int MODE, int LPT, bool FULL, bool HOT = false>
+// nested walk, action prefetch on.  Level 2 - the same with a fixed prefix allowed (traffic-model CUEs) and the 16-byte fused
+// LinearObs expansion, for several small envs per workgroup.  Twelve scalar compare-and-branch pairs and the code behind
+// their other arms leave the instruction stream (the kernel's SQ_WAIT_INST_ANY - waves waiting to be issued - is a quarter of its wave cycles).
+template <int MODE, int LPT, bool FULL, int HOT = 0>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr int KEEP = LPT > 0 ? LPT : 1;
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) {
         const int i = lt + u * TPE;
-        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT);
+        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1);
     }
     // ---- pass 0: clear masks and flags
     const bool want_masks = HOT || (W > 0 && !ABL(4));
@@ -400,9 +401,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) me0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT);
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1);
         int rb, p;
-        decode_link(a, in, act_row, rb, p, cfg_action_mode, HOT);
+        decode_link(a, in, act_row, rb, p, cfg_action_mode, HOT == 1);
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(p) * in.rb_.x, __int_as_float(rb));
         s.link[i] = tuple;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
         for (int u = 0; u < KEEP; ++u) {
             const int i = lt + u * TPE;
-            const int col = HOT || i < a.act_stride ? i : a.act_stride - 1;
+            const int col = HOT == 1 || i < a.act_stride ? i : a.act_stride - 1;
             pf ^= *at(a.actions, fresh(((unsigned)bp * (unsigned)a.act_stride + (unsigned)col) * 4u));
         }
     }
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     int my_flags = 0;
     bool violated = false;
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT);   // strided links: records re-read (L2)
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1);   // strided links: records re-read (L2)
         const float4 me = IN_REGS(u) ? me0[KEPT(u)] : s.link[i];
         const float2 rx = make_float2(in.pos.z, in.pos.w);
         const int rb = __float_as_int(me.w);
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             t[1] = rx;
             t[2] = make_float2(sinr_db, snr_db);
         }
-        if (!FULL && a.fuse_obs) {
+        if (!FULL && (HOT == 2 || a.fuse_obs)) {
             float2* t = reinterpret_cast<float2*>(s.tflat + 6 * i);
             t[0] = make_float2(me.x, me.y);
             t[1] = rx;
@@ -756,11 +757,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // ---- pass 4 (small N only): LinearObs expansion of this workgroup's envs, obs_fn.py:43-53.  Every thread of the
     // workgroup streams 16-byte (or 8-byte, odd N) stores over the contiguous [N][6N] block of each env; tflat was
     // published by the reward pass's barrier.  Same mapping as csrc/d2d_obs.hip (bit-identical output).
-    if (!FULL && a.fuse_obs) {
+    if (!FULL && (HOT == 2 || a.fuse_obs)) {
         const unsigned T = blockDim.x, q_per_row = a.obs_q_per_row, total = (unsigned)N * q_per_row;
         const unsigned row_floats = 6u * (unsigned)N;
         const unsigned RP = T / q_per_row;                  // whole obs rows one pass of the workgroup covers
-        if (a.fuse_obs == 4 && RP >= 1u) {
+        if (HOT == 2 || (a.fuse_obs == 4 && RP >= 1u)) {
             // Fixed (row-in-pass r, float4 column q) per thread: the source of output column f in row i is 6i + f for f < 6
             // (the agent's own six values), else f - 6 once i >= f / 6 (links before the agent shift by one slot), else f.
             // Thresholds and both candidates are per-thread constants, so a store costs two compares + selects instead of
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         __builtin_nontemporal_store(v, out + (size_t)i * q_per_row);
                     }
             }
-        } else {
+        } else if (HOT != 2) {
             for (int el = 0; el < a.epw; ++el) {
                 const int be = blockIdx.x * a.epw + el;
                 if (be >= a.B) break;
@@ -863,6 +864,12 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
                      a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
+    // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
+    // (traffic-model CUEs) allowed
+    const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
+                      a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && a.ablate == 0 && a.mask_words > 0 &&
+                      a.fuse_obs == 4 && a.obs_q_per_row > 0 && (unsigned)block_threads / a.obs_q_per_row >= 1u &&
+                      (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
@@ -875,7 +882,8 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     } while (0)
 #define D2D_LAUNCH(M)                                                                                    \
     do {                                                                                                 \
-        if (lpt == 1 && full && hot) D2D_LAUNCH_1(M, 1, true, true);                                     \
+        if (lpt == 1 && full && hot) D2D_LAUNCH_1(M, 1, true, 1);                                        \
+        else if (lpt == 1 && !full && hot2) D2D_LAUNCH_1(M, 1, false, 2);                                \
         else if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true);                                             \
         else if (lpt == 2) D2D_LAUNCH_1(M, 2, false);                                                    \
         else if (lpt == 1 && full) D2D_LAUNCH_1(M, 1, true);                                             \
