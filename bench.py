@@ -514,7 +514,7 @@ def attach_traffic(roof, args, w):
         if rec.get('workload_key') != f'{args.workload}/{args.obs}':
             continue
         for kname, d in rec.get('kernels', {}).items():
-            if roof['kernel'] in kname and 'hbm_bytes_per_launch' in d:
+            if roof['kernel'].split(' ')[0] in kname and 'hbm_bytes_per_launch' in d:
                 if rec.get('source_digest') == digest:
                     roof['traffic'] = d['hbm_bytes_per_launch']
                     roof['traffic_source'] = (f'profiles/{path.name} (WRITE_SIZE + 2*FETCH_SIZE, separate --pmc passes; '
