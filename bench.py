@@ -74,28 +74,97 @@ def _cpu_chunk(job):
     return envs * done, time.perf_counter() - t0
 
 
+def effective_cores():
+    """Cores this process can really use: its affinity mask, capped by the cgroup CPU quota (a container that sees 256
+    cores may be entitled to 16 of them: more workers than that only time-share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path('/sys/fs/cgroup/cpu.max').read_text().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read_text())
+            per = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read_text())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
+def _c_oracle_leg(w, seconds, threads):
+    """The C restatement of the oracle (oracle/c/d2d_oracle.c) on the same workload, obs materialised, for `seconds`."""
+    from oracle import c_oracle
+    from oracle import d2d_oracle as orc
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from sim_util import default_links, random_layout
+    c, p, r = w['cues'], w['dues'], w['rbs']
+    n = c + p
+    envs = max(threads, 1) * (1 if n > 100 else 32)
+    rng = np.random.default_rng(4321)
+    ids, cfgs, is_bs = orc.device_configs(c, p)
+    cols = orc.device_columns(cfgs, is_bs)
+    tx, rx, ty = default_links(c, p)
+    pos = random_layout(rng, envs, c, p).astype(np.float64)
+    raws = [np.concatenate([rng.integers(0, r * 24, (envs, c)), rng.integers(0, r * 21, (envs, p))], 1) for _ in range(3)]
+    out = c_oracle.full_step(pos, tx, rx, ty, raws[0], cols, orc.PathLossSpec(), threads=threads)      # allocates + warms up
+    t0 = time.perf_counter()
+    calls = 0
+    while calls == 0 or time.perf_counter() - t0 < seconds:
+        c_oracle.full_step(pos, tx, rx, ty, raws[calls % 3], cols, orc.PathLossSpec(), threads=threads, out=out)
+        calls += 1
+    dt = time.perf_counter() - t0
+    return envs * calls * n / dt, envs * calls, dt
+
+
 def cpu_baseline(w, seconds_budget=16.0):
-    """Time the NumPy fp64 oracle (a port of the reference's algorithm; the Python reference cannot travel to this
-    box) on a bounded sample of the same workload, including the materialised LinearObs: one thread (`value`), and a
-    process pool over env chunks on every core this process may run on (`all_cores`).  Both legs are bounded by
-    wall-clock deadlines (about seconds_budget in total).  Runs BEFORE this process initialises HIP, so forking workers
-    is safe."""
+    """The oracle - a port of the reference's algorithm; the Python reference cannot travel to this box - timed on a
+    bounded sample of the same workload, LinearObs materialised (float64, as the reference's arrays are).  `value` is the
+    plain-C restatement on one thread, `all_cores` the same with OpenMP over envs on every core this process may use;
+    `numpy_oracle` holds the NumPy restatement's figures (one thread, and a process pool over every core).  Every leg is
+    bounded by a wall-clock deadline.  Runs BEFORE this process initialises HIP, so forking workers is safe."""
+    n = w['cues'] + w['dues']
+    cores = effective_cores()
+    out = {}
+    try:
+        v1, steps1, dt1 = _c_oracle_leg(w, 4.0, 1)
+        out = {'value': v1, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
+               'sample': f'{steps1} env-steps of the same workload ({steps1 * n} agent-steps, obs materialised in float64), '
+                         f'C restatement of the oracle (oracle/c/d2d_oracle.c, gcc -O2), one thread, {dt1:.1f} s; host has '
+                         f'{os.cpu_count()} cores',
+               'reference_pure_python_1core_build_container': 6.3e3 if n > 100 else 3.3e4}
+        va, stepsa, dta = _c_oracle_leg(w, 4.0, cores)
+        out['all_cores'] = {'value': va, 'unit': 'agent-steps/s', 'cores': cores,
+                            'sample': f'{stepsa} env-steps, OpenMP over envs on {cores} threads (affinity mask capped by the '
+                                      f'cgroup CPU quota; the host shows {os.cpu_count()} cores), {dta:.1f} s'}
+    except Exception as exc:                      # pragma: no cover - a baseline failure must not lose the GPU number
+        out['c_oracle_error'] = repr(exc)
+    numpy_leg = _numpy_baseline(w, seconds_budget)
+    if 'value' not in out:
+        numpy_leg.update(out)
+        return numpy_leg
+    out['numpy_oracle'] = numpy_leg
+    return out
+
+
+def _numpy_baseline(w, seconds_budget):
+    """The NumPy fp64 oracle: one thread, and a process pool over env chunks on every core."""
     c, p, r = w['cues'], w['dues'], w['rbs']
     n = c + p
     envs = 8 if n > 100 else 128
-    done, dt = _cpu_chunk((c, p, r, envs, 1 << 30, 1234, time.time() + 0.4 * seconds_budget))
+    done, dt = _cpu_chunk((c, p, r, envs, 1 << 30, 1234, time.time() + 0.3 * seconds_budget))
     single = done * n / dt
     out = {'value': single, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
            'sample': f'{done} env-steps of the same workload ({done * n} agent-steps, obs materialised), '
-                     f'NumPy fp64 oracle, single thread, {dt:.1f} s; host has {os.cpu_count()} cores',
-           'reference_pure_python_1core_build_container': 6.3e3 if n > 100 else 3.3e4}
+                     f'NumPy fp64 oracle, single thread, {dt:.1f} s; host has {os.cpu_count()} cores'}
     # -- every core: one process per core (NumPy elementwise code holds the GIL; BLAS threads pinned to 1)
     try:
         import multiprocessing as mp
-        cores = len(os.sched_getaffinity(0))
+        cores = effective_cores()
         with mp.get_context('fork').Pool(cores) as pool:
             t0 = time.perf_counter()
-            deadline = time.time() + 0.4 * seconds_budget
+            deadline = time.time() + 0.3 * seconds_budget
             res = pool.map(_cpu_chunk, [(c, p, r, envs, 1 << 30, 1000 + k, deadline) for k in range(cores)], chunksize=1)
             wall = time.perf_counter() - t0
         total = sum(d for d, _ in res)

@@ -12,6 +12,9 @@ the imported reference in the build container (``tests/golden/make_golden.py``);
 relative) and against the known-answer values in the reference's own unit tests
 (test_path_loss.py, test_conversion.py, test_device.py).
 
+A second, independently written restatement in plain C lives in ``oracle/c/d2d_oracle.c`` (front end:
+``oracle/c_oracle.py``; log-distance model only); ``tests/test_oracle_c.py`` holds it to this module and to the goldens.
+
 Everything follows the reference's dB-domain arithmetic literally, in float64, batched
 over a leading env axis B.  Citations are ``file:line`` under /root/reference/src/gym_d2d.
 
