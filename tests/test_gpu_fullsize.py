@@ -150,3 +150,29 @@ def test_baseline_config_4_at_full_size():
     counts = (rb[sample][:, :, None] == rb[sample][:, None, :]).sum(axis=2)
     assert (obs[:, :, 7].cpu().numpy()[sample] == counts).all()
     env.close()
+
+
+def test_full_size_every_link_against_the_c_oracle(big_env):
+    """All 4096 x 512 links of one step - SINR, SNR, rate, capacity, reward, compact table - against the plain-C
+    restatement of the oracle (float64, OpenMP over envs: a few seconds for the 2.1 M links that the NumPy oracle would
+    need minutes for).  Together with the every-element obs layout identity above, that is the whole output of a
+    BASELINE-size step checked against the reference's algorithm."""
+    import torch
+    from oracle import c_oracle
+    env = big_env
+    env.reset(seed=77)
+    act = _actions(torch, env.device, 11)
+    _, rew, _, info = env.step(act)
+    torch.cuda.synchronize()
+    assert env.status_flags() == 0
+    tx, rx, ty = default_links(C, P)
+    ids, cfgs, is_bs = orc.device_configs(C, P)
+    cols = orc.device_columns(cfgs, is_bs)
+    pos = env.simulator.positions().astype(np.float64)
+    ref = c_oracle.full_step(pos, tx, rx, ty, act.cpu().numpy(), cols, orc.PathLossSpec(), with_obs=False,
+                             threads=min(16, c_oracle.max_threads()))
+    assert np.array_equal(info['rb'].cpu().numpy(), ref['rb']) and np.array_equal(info['tx_pwr_dbm'].cpu().numpy(), ref['pwr'])
+    for f in ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps'):
+        assert rel_err(info[f].cpu().numpy(), ref[f]) <= TOL, f
+    assert rel_err(rew[:, 0].cpu().numpy(), ref['reward']) <= TOL
+    assert rel_err(env._t['table'].cpu().numpy(), ref['table']) <= TOL
