@@ -211,15 +211,6 @@ __device__ __forceinline__ T* at(T* base, unsigned byte_off) {
     return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
 }
 
-// Result stores: streaming (nt) in the one-env-per-workgroup kernels - 109 MB per launch that this launch never reads
-// again would otherwise push the link records and the prefetched action rows out of the 4 MB L2s (-0.7 us at 4096 x 512) -
-// plain in the small-env kernels, whose whole output stays cache resident for the consumer (nt: +0.25 us at 1024 x 50).
-template <bool NT, class T>
-__device__ __forceinline__ void put(T v, T* p) {
-    if (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
-
 // Everything the kernel needs about one link, as it comes out of memory.  The loads are INDEPENDENT of one another
 // (no link -> device -> position double hop, no power-table lookup, no per-type constant fetched behind the record):
 // they are issued back to back in the prologue and first used after pass 0's barrier.
@@ -421,7 +412,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                                                                          // route wants the type, and reads it from the record)
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
-        if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); put<FULL>(rb, at(a.rb_out, oe)); put<FULL>(p, at(a.pwr_out, oe)); }
+        if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); *at(a.rb_out, oe) = rb; *at(a.pwr_out, oe) = p; }
         if (want_masks && !ABL(2)) {
             const unsigned bit = 1u << (i & 31);
             if (LIKELY((unsigned)rb < (unsigned)R)) {
@@ -622,17 +613,17 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 
         if (!ABL(8)) {
             const unsigned o4 = fresh((row + (unsigned)i) * 4u);
-            put<FULL>(sinr_db, at(a.sinr_db, o4));
-            put<FULL>(snr_db, at(a.snr_db, o4));
-            put<FULL>(rate, at(a.rate, o4));
-            put<FULL>(cap, at(a.cap, o4));
+            *at(a.sinr_db, o4) = sinr_db;
+            *at(a.snr_db, o4) = snr_db;
+            *at(a.rate, o4) = rate;
+            *at(a.cap, o4) = cap;
         }
         if (cfg_write_table && !ABL(16)) {                                 // obs_fn.py:57-60
             const unsigned o4t = fresh((row + (unsigned)i) * 4u);
-            f32x2* t = reinterpret_cast<f32x2*>(at(a.table, (o4t << 2) + (o4t << 1)));        // 24 bytes per link, no v_mul_lo
-            put<FULL>(f32x2{me.x, me.y}, t);
-            put<FULL>(f32x2{rx.x, rx.y}, t + 1);
-            put<FULL>(f32x2{sinr_db, snr_db}, t + 2);
+            float2* t = reinterpret_cast<float2*>(at(a.table, (o4t << 2) + (o4t << 1)));      // 24 bytes per link, no v_mul_lo
+            t[0] = make_float2(me.x, me.y);
+            t[1] = rx;
+            t[2] = make_float2(sinr_db, snr_db);
         }
         if (!FULL && (HOT == 2 || a.fuse_obs)) {
             float2* t = reinterpret_cast<float2*>(s.tflat + 6 * i);
