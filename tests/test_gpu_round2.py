@@ -462,3 +462,36 @@ def test_action_decode_is_exact_for_every_magnitude(native):
     assert np.array_equal(info['rb'].cpu().numpy(), acts // levels[None, :])
     assert np.array_equal(info['tx_pwr_dbm'].cpu().numpy(), acts % levels[None, :])
     env.close()
+
+
+@pytest.mark.parametrize('shape', [(37, 64, 64, 16, 'agent'), (64, 25, 25, 25, 'traffic')])
+def test_rollout_specialisations_are_bit_identical_to_the_generic_kernel(native, shape):
+    """The compile-time specialisations of the rollout configuration (HOT level 1: one env per workgroup; level 2: small
+    envs sharing a workgroup with the fused LinearObs expansion) against the generic kernel with every choice made at
+    run time (selected here by switching the action prefetch off, one of the conditions of the specialisations):
+    every output of several steps, bit for bit."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
+    B, C, P, R, cue = shape
+    obs_fn = OwnLinkObsFunction if cue == 'agent' else LinearObsFunction
+    outs = {}
+    for prefetch in (-1, 0):
+        env = VecD2DEnv({'num_rbs': R, 'num_cues': C, 'num_due_pairs': P, 'obs_fn': obs_fn}, num_envs=B, cue_actions=cue)
+        env.reset(seed=21)
+        env.simulator.handle.set_tuning(native.TUNE_STEP_PREFETCH, prefetch)
+        g = torch.Generator(device=env.device).manual_seed(3)
+        snaps = []
+        for k in range(3):
+            act = torch.randint(0, R * 21, (B, env.num_agents), device=env.device, generator=g, dtype=torch.int32)
+            obs, rew, _, info = env.step(act)
+            torch.cuda.synchronize()
+            snaps.append({n: v.clone() for n, v in dict(info, rew=rew, obs=obs, table=env._t['table'], flags=env._t['env_flags']).items()
+                          if torch.is_tensor(v)})
+        outs[prefetch] = snaps
+        env.close()
+    for k in range(3):
+        for n, v in outs[-1][k].items():
+            w = outs[0][k][n]
+            same = torch.equal(v, w) if not v.is_floating_point() else torch.equal(v.view(torch.int32), w.view(torch.int32))
+            assert same, (k, n)
