@@ -78,6 +78,7 @@ SIGNATURES = {
     'd2d_set_reward': (C.c_int, [_P, _I, C.c_float]),
     'd2d_set_obs_mode': (C.c_int, [_P, _I]),
     'd2d_set_bucketing': (C.c_int, [_P, _I]),
+    'd2d_set_export_actions': (C.c_int, [_P, _I]),
     'd2d_set_tuning': (C.c_int, [_P, _I, _I]),
     'd2d_get_buffer': (C.c_int, [_P, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     'd2d_bind_buffer': (C.c_int, [_P, _I, _P, C.c_size_t]),
@@ -215,6 +216,9 @@ class Handle:
 
     def set_bucketing(self, enabled: bool) -> None:
         _check(self._lib.d2d_set_bucketing(self._h, int(enabled)))
+
+    def set_export_actions(self, enabled: bool) -> None:
+        _check(self._lib.d2d_set_export_actions(self._h, int(enabled)))
 
     def set_tuning(self, key: int, value: int) -> None:
         _check(self._lib.d2d_set_tuning(self._h, key, value))

@@ -92,6 +92,7 @@ struct d2d_handle {
     float reward_param = 0.0f;
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
+    int export_actions = 1;                          // d2d_step writes the decoded (rb, pwr) to D2D_BUF_RB / D2D_BUF_PWR
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
     int num_cus = 0;
     int tune_step_prefetch = -1;                     // action prefetch distance in envs: -1 auto, 0 off
@@ -363,13 +364,18 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     }
     // per-RB membership masks: u32 words, every link of the env in some thread's registers, N <= 1024 (the 32-bit summary
     // word names up to 32 mask words)
+    // per-RB member lists (walk 2): any N whose links sit in registers; an env that overflows a list falls back to the masks
+    // when they exist, else to the all-pairs sweep
+    int lists = h->bucketing && s.walk == 2 && lpt > 0 && s.reward_fn != D2D_REWARD_CUE_SINR_SHANNON;
+    if (s.walk == 2 && !lists) s.walk = 0;
     int W = 0;
     if (h->bucketing && lpt > 0 && N <= 1024) {
         W = (N + 31) / 32;
-        if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode) > 96 * 1024) W = 0;
+        if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) W = 0;
     }
+    if (lists && d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) { lists = 0; s.walk = 0; }
     s.lpt = lpt;
-    d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, &s.lds);
+    d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, &s.lds);
     const size_t env_lds = s.lds.env_bytes;
     if (env_lds > 160 * 1024) return fail(D2D_ERR_UNSUPPORTED, "links per env exceed the LDS staging capacity");
     int epw = h->tune_step_epw;
@@ -425,7 +431,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         if (s.write_table) s.table = redirect->table;
         if (h->obs_mode == D2D_OBS_LINEAR) s.obs = redirect->obs;
     } else {
-        if (action_mode == 0) {
+        if (action_mode == 0 && h->export_actions) {
             GET(D2D_BUF_RB, rb_out, int*);
             GET(D2D_BUF_PWR, pwr_out, int*);
         }
@@ -739,6 +745,12 @@ int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode) {
     return D2D_OK;
 }
 
+int d2d_set_export_actions(d2d_handle* h, int32_t enabled) {
+    if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    h->export_actions = enabled ? 1 : 0;
+    return D2D_OK;
+}
+
 int d2d_set_bucketing(d2d_handle* h, int32_t enabled) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
@@ -790,7 +802,7 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
             h->tune_step_lpt = value;
             break;
         case D2D_TUNE_STEP_WALK:
-            if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "walk must be -1, 0 or 1");
+            if (value < -1 || value > 2) return fail(D2D_ERR_INVALID, "walk must be -1, 0, 1 or 2");
             h->tune_step_walk = value;
             break;
         case D2D_TUNE_STEP_ABLATE:

@@ -28,7 +28,7 @@ enum PlMode : int {
 
 // Byte offsets of one env's LDS arrays (step_lds_layout): only what the configuration reads back is allocated.
 struct StepLds {
-    unsigned aux, rx, sinr, sh, expo, tflat, mask, env_bytes;
+    unsigned aux, rx, sinr, sh, expo, tflat, mask, lists, env_bytes;
 };
 
 struct StepArgs {
@@ -46,7 +46,9 @@ struct StepArgs {
     float inv_n;             // 1 / N
     int epw;                 // envs per workgroup (epw * tpe <= blockDim)
     int prefetch_envs;       // software-prefetch distance for the action rows, in envs (multiple of 8 * epw; 0 = off)
-    int walk;                // mask walk loop shape: 0 nested (words outside, members inside), 1 flattened
+    int walk;                // same-RB search: 0 mask walk, nested (words outside, members inside), 1 mask walk, flattened,
+                             // 2 per-RB member lists (slot counter + eight u16 slots per RB, sorted in registers by the receiver;
+                             // an env in which some RB holds more than eight links rebuilds the masks and walks them)
     int reward_fn;
     float reward_param;
     int write_table;
@@ -104,8 +106,8 @@ struct ObsArgs {
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream);
-size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode);
-void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, StepLds* out);
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists);
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out);
 hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);
 hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const int4* rec_a, int B, int N, int D,
                                  float4* lpos, hipStream_t stream);

@@ -154,29 +154,37 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
 // At N = 512, R = 256, inverse-square path loss, SystemCapacity: 10.3 KB + 17.4 KB masks = 27.7 KB per env.
 #define LDS_HEAD_BYTES 80u
 
-void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, StepLds* out) {
-    unsigned off = LDS_HEAD_BYTES + (unsigned)N * 16u;
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out) {
+    // lists: one more tuple (and exponent) behind the last link - the far-away, zero-power stand-in an empty list slot reads
+    const unsigned NL = (unsigned)N + (lists ? 1u : 0u);
+    unsigned off = LDS_HEAD_BYTES + NL * 16u;
     out->aux = off; off += (unsigned)N * 4u;
     out->rx = off; if (lpt == 0) off += (unsigned)N * 8u;
     out->sinr = off; out->sh = off + (unsigned)N * 4u; if (reward_fn >= 2) off += (unsigned)N * 8u;
-    out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW) off += (unsigned)N * 4u;
+    out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW) off += NL * 4u;
     off = (off + 7u) & ~7u;
     out->tflat = off; if (fuse_obs) off += (unsigned)N * 24u;
     off = (off + 15u) & ~15u;                            // the mask region is cleared with 16-byte stores
     out->mask = off;
     if (mask_words > 0) off += ((unsigned)R * mask_words + mask_words + (unsigned)R) * 4u;
+    off = (off + 15u) & ~15u;
+    // member lists: slots[R] (eight u16 link indices per RB, 0xFFFF = empty) then cnt[R] u32 (padded to 16 bytes) -
+    // one contiguous region, (re)initialised with one 16-byte store per lane
+    out->lists = off;
+    if (lists) off += (unsigned)R * 16u + (((unsigned)R + 3u) & ~3u) * 4u;
     out->env_bytes = (off + 15u) & ~15u;
 }
 
-size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode) {
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists) {
     StepLds l;
-    step_lds_layout(N, R, mask_words, fuse_obs, lpt, reward_fn, mode, &l);
+    step_lds_layout(N, R, mask_words, fuse_obs, lpt, reward_fn, mode, lists, &l);
     return l.env_bytes;
 }
 
 struct Smem {
     float* red; int* flags; float4* link; float2* rx; float* sinr; float* sh; float* expo; int* aux; float* tflat;
     unsigned* mask; unsigned* side; unsigned* summ;
+    uint4* slots; unsigned* cnt;
 };
 
 __device__ __forceinline__ Smem carve(unsigned char* base, const StepLds& l, unsigned R, unsigned W) {
@@ -193,6 +201,8 @@ __device__ __forceinline__ Smem carve(unsigned char* base, const StepLds& l, uns
     s.mask = reinterpret_cast<unsigned*>(base + l.mask);
     s.side = s.mask + R * W;
     s.summ = s.side + W;
+    s.slots = reinterpret_cast<uint4*>(base + l.lists);
+    s.cnt = reinterpret_cast<unsigned*>(base + l.lists + R * 16u);
     return s;
 }
 
@@ -298,6 +308,38 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
     return f < 6u ? head + f : (f < head + 6u ? f - 6u : f);
 }
 
+// Ascending sort of eight keys in registers (Batcher's odd-even merge sort, 19 compare-exchanges = 38 VALU, no branches): the
+// receiver's view of its RB's member list.  Empty slots hold 0xFFFF and sink to the end.
+__device__ __forceinline__ void sort8(unsigned (&v)[8]) {
+#define D2D_CE(x, y) { const unsigned lo_ = min(v[x], v[y]); v[y] = max(v[x], v[y]); v[x] = lo_; }
+    D2D_CE(0, 1) D2D_CE(2, 3) D2D_CE(4, 5) D2D_CE(6, 7)
+    D2D_CE(0, 2) D2D_CE(1, 3) D2D_CE(4, 6) D2D_CE(5, 7)
+    D2D_CE(1, 2) D2D_CE(5, 6)
+    D2D_CE(0, 4) D2D_CE(1, 5) D2D_CE(2, 6) D2D_CE(3, 7)
+    D2D_CE(2, 4) D2D_CE(3, 5)
+    D2D_CE(1, 2) D2D_CE(3, 4) D2D_CE(5, 6)
+#undef D2D_CE
+}
+
+#define LIST_EMPTY 0xFFFFu
+#define LIST_SLOTS 8
+
+// masks + sidelink words + summaries of one env, 16 bytes per store (the region is 16-byte aligned and padded)
+template <bool FULL>
+__device__ __forceinline__ void clear_masks(const Smem& s, int R, int W, int lt, int TPE) {
+    uint4* m16 = reinterpret_cast<uint4*>(s.mask);
+    const int n16 = (R * W + W + R + 3) >> 2;
+    if (FULL) {
+        // whole rounds with a wave-uniform trip count (scalar loop, no exec masking), then one predicated tail
+        int k0 = 0;
+#pragma unroll 1
+        for (; k0 + TPE <= n16; k0 += TPE) m16[lt + k0] = make_uint4(0u, 0u, 0u, 0u);
+        if (lt < n16 - k0) m16[lt + k0] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int k = lt; k < n16; k += TPE) m16[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // LPT  = links per thread held in registers: 1 (thread = link, N <= tpe), 2 (links lt and lt + tpe: half the waves per
 //        env, two independent dependency chains per wave), 0 = strided (N > 2 * 1024: records re-read per link).
 // FULL = LPT > 0, one env per workgroup and N == LPT * blockDim: every lane owns exactly LPT links of an existing env, so
@@ -328,15 +370,23 @@ __device__ __forceinline__ unsigned obs_src_col(unsigned f, unsigned i) {
 // nested walk, action prefetch on.  Level 2 - the same with a fixed prefix allowed (traffic-model CUEs) and the 16-byte fused
 // LinearObs expansion, for several small envs per workgroup.  Twelve scalar compare-and-branch pairs and the code behind
 // their other arms leave the instruction stream (the kernel's SQ_WAIT_INST_ANY - waves waiting to be issued - is a quarter of its wave cycles).
-template <int MODE, int LPT, bool FULL, int HOT = 0>
+// LISTS: same-RB interferers come from per-RB member lists instead of the membership masks (StepArgs::walk == 2).  Pass 1 draws
+// a slot from the RB's counter (ds_add_rtn_u32) and writes its link index there (ds_write_b16); a receiver reads its RB's
+// eight slots with ONE ds_read_b128, takes its own entry out, sorts the rest in registers (ascending link index: the same
+// accumulation order as the mask walk and the all-pairs sweep, hence the same bits) and then knows every interferer at once -
+// three dependent LDS round trips (list, tuples) instead of the mask walk's summary -> word -> tuple chain per word, and 5 KB
+// to initialise per env instead of 17 KB of masks.  An env in which some RB drew a ninth link (6 % of envs under uniformly
+// random actions at 512 links on 256 RBs) raises a workgroup flag; its workgroup then clears and builds the masks behind two
+// extra barriers and walks them, so the cost stays proportional to the same-RB pairs for any action distribution.
+template <int MODE, int LPT, bool FULL, int HOT = 0, bool LISTS = false>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr int KEEP = LPT > 0 ? LPT : 1;
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
     const int cfg_col_mode = HOT ? 0 : a.col_mode;
     const int cfg_reward_fn = HOT ? 1 : a.reward_fn;
     const int cfg_write_table = HOT ? 1 : a.write_table;
-    const int cfg_walk = HOT ? 0 : a.walk;
-    const bool cfg_export_actions = HOT ? true : a.rb_out != nullptr;
+    const int cfg_walk = (HOT || LISTS) ? 0 : a.walk;
+    const bool cfg_export_actions = a.rb_out != nullptr;          // the info dict's rb / tx_pwr_dbm (d2d_set_export_actions)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int N = a.N, R = a.R, D = a.D, W = a.mask_words, TPE = a.tpe;
     const int tid = threadIdx.x;
@@ -349,6 +399,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     const unsigned row = (unsigned)b * (unsigned)N;
     const unsigned act_row = (unsigned)b * (unsigned)a.act_stride;
     Smem s = carve(smem_raw + (FULL ? 0u : (unsigned)(e < a.epw ? e : 0) * a.lds.env_bytes), a.lds, R, W);
+    int* wg_flags = reinterpret_cast<int*>(smem_raw + 64);       // flags[] of env slot 0: [3] = some RB of some env of this workgroup overflowed its list
     STAMP(0);
     if (ABL(1024)) {                      // diagnostic: workgroup launch only
         if (tid == 4095) a.env_flags[b] = 1;
@@ -366,22 +417,19 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1);
     }
     // ---- pass 0: clear masks and flags
-    const bool want_masks = HOT || (W > 0 && !ABL(4));
+    const bool have_masks = HOT || W > 0;                          // mask region allocated
+    const bool want_masks = !LISTS && (HOT || (W > 0 && !ABL(4)));  // masks built in pass 1 (LISTS: only by an overflowing env, later)
     if (active) {
-        if (want_masks) {
-            // masks + sidelink words + summaries, 16 bytes per store (the region is 16-byte aligned and padded)
-            uint4* m16 = reinterpret_cast<uint4*>(s.mask);
-            const int n16 = (R * W + W + R + 3) >> 2;
-            if (FULL) {
-                // whole rounds with a wave-uniform trip count (scalar loop, no exec masking), then one predicated tail
-                int k0 = 0;
+        if (LISTS) {
+            // slots[R] <- 0xFFFF.., cnt[R] <- 0: one contiguous region, one 16-byte store per lane and round
+            const int nl = R + ((R + 3) >> 2);
 #pragma unroll 1
-                for (; k0 + TPE <= n16; k0 += TPE) m16[lt + k0] = make_uint4(0u, 0u, 0u, 0u);
-                if (lt < n16 - k0) m16[lt + k0] = make_uint4(0u, 0u, 0u, 0u);
-            } else {
-                for (int k = lt; k < n16; k += TPE) m16[k] = make_uint4(0u, 0u, 0u, 0u);
+            for (int k = lt; k < nl; k += TPE) { const unsigned f = k < R ? 0xFFFFFFFFu : 0u; s.slots[k] = make_uint4(f, f, f, f); }
+            if (lt == TPE - 1) {
+                s.link[N] = make_float4(1.0e18f, 1.0e18f, 0.0f, __int_as_float(-1));
+                if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[N] = 2.0f;
             }
-        }
+        } else if (want_masks) clear_masks<FULL>(s, R, W, lt, TPE);
         if (lt < 5) reinterpret_cast<uint4*>(s.red)[lt] = make_uint4(0u, 0u, 0u, 0u);   // red[16] + flags[4]: 80 bytes
     }
     // nothing that consumes a loaded value may be scheduled above this barrier: the wave would sit on the HBM round trip
@@ -398,8 +446,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 
     // ---- pass 1: decode + stage the transmitter side of every link
     float4 me0[KEEP];
+    unsigned myslot[KEEP];                                               // LISTS: where this link sits in its RB's list
 #pragma unroll
-    for (int u = 0; u < KEEP; ++u) me0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < KEEP; ++u) { me0[u] = make_float4(0.f, 0.f, 0.f, 0.f); myslot[u] = 0u; }
     FOR_MY_LINKS(u, i) {
         const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1);
         int rb, p;
@@ -413,6 +462,16 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
         if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); *at(a.rb_out, oe) = rb; *at(a.pwr_out, oe) = p; }
+        if (LISTS) {
+            if (LIKELY((unsigned)rb < (unsigned)R)) {
+                const unsigned slot = atomicAdd(&s.cnt[rb], 1u);                         // ds_add_rtn_u32
+                if (LIKELY(slot < (unsigned)LIST_SLOTS)) reinterpret_cast<unsigned short*>(s.slots)[(unsigned)rb * LIST_SLOTS + slot] = (unsigned short)i;
+                else atomicOr(&wg_flags[3], 1);
+                if (IN_REGS(u)) myslot[KEPT(u)] = slot;
+            }
+            else atomicOr(&s.flags[0], FLAG_RB_OOR);
+            if (cfg_reward_fn == 3 && have_masks && (i & 31) == 0) s.side[i >> 5] = a.side_words[i >> 5];
+        }
         if (want_masks && !ABL(2)) {
             const unsigned bit = 1u << (i & 31);
             if (LIKELY((unsigned)rb < (unsigned)R)) {
@@ -428,7 +487,27 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     STAMP(3);
     if (!ABL(64)) __syncthreads();
     STAMP(4);
-    const bool masks_on = want_masks && active;
+    // LISTS: did any RB of any env of this workgroup draw a ninth link?  Then every env of the workgroup builds its masks now
+    // (two more barriers, workgroup-uniform) and walks them instead.
+    bool lists_on = false, masks_late = false;
+    if (LISTS) {
+        const bool ovf = __builtin_amdgcn_readfirstlane(wg_flags[3]) != 0;
+        lists_on = !ovf && active;
+        if (UNLIKELY(ovf) && have_masks) {
+            if (active) clear_masks<FULL>(s, R, W, lt, TPE);
+            __syncthreads();
+            FOR_MY_LINKS(u, i) {
+                const int rb = IN_REGS(u) ? __float_as_int(me0[KEPT(u)].w) : __float_as_int(s.link[i].w);
+                if ((unsigned)rb < (unsigned)R) {
+                    atomicOr(&s.mask[__umul24((unsigned)(i >> 5), (unsigned)R) + (unsigned)rb], 1u << (i & 31));
+                    atomicOr(&s.summ[rb], 1u << (i >> 5));
+                }
+            }
+            __syncthreads();
+            masks_late = true;
+        }
+    }
+    const bool masks_on = (LISTS ? masks_late : want_masks) && active;
     const bool skip_walk = ABL(7);
     if (ABL(512)) {                       // diagnostic: everything up to the end of pass 1
         if (me0[0].z == 1.2345f) a.env_flags[b] = 1;
@@ -474,7 +553,59 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         float acc = 0.0f;
         int dmin = 0x7F000000;                                           // bits of the smallest squared distance met (d2 >= 0:
                                                                          // integer order == float order); 0 <=> 'math domain error'
+        const bool use_lists = LISTS && IN_REGS(u) && lists_on && (unsigned)rb < (unsigned)R;
         if (skip_walk) {
+        } else if (LISTS && LIKELY(use_lists)) {
+            // the RB's eight slots in one read; this link's own entry out (.difference({action}), simulator.py:95) - its slot
+            // came back from the counter in pass 1; the others ascending
+            uint4 m = s.slots[rb];
+            const unsigned sl = myslot[KEPT(u)];
+            const unsigned own = LIST_EMPTY << ((sl & 1u) << 4), q = sl >> 1;
+            m.x |= q == 0u ? own : 0u; m.y |= q == 1u ? own : 0u; m.z |= q == 2u ? own : 0u; m.w |= q == 3u ? own : 0u;
+            unsigned v[8] = {m.x & 0xFFFFu, m.x >> 16, m.y & 0xFFFFu, m.y >> 16, m.z & 0xFFFFu, m.z >> 16, m.w & 0xFFFFu, m.w >> 16};
+            sort8(v);
+#define D2D_LIST_PAIR(o, j)                                                                                             \
+            {                                                                                                           \
+                const float dx = (o).x - rx.x, dy = (o).y - rx.y;                                                       \
+                const float d2 = fmaf(dx, dx, dy * dy);                                                                 \
+                float g;                                                                                                \
+                if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];                                \
+                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); } \
+                if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, (int)(j), i, 0u);              \
+                acc = fmaf((o).z, g, acc);                               /* simulator.py:97-101, linear mW */            \
+            }
+            if (MODE == PL_INV_SQUARE || MODE == PL_POWER) {
+                // Empty slots are clamped onto the stand-in tuple at link[N] (zero power, 1e18 m away): fmaf(0, g, acc) leaves acc
+                // untouched, so the steps need no predication and their tuple reads go out together - four, then two, then one,
+                // each batch only if some lane of the wave still has a member (sorted: a lane's members are a prefix).
+                unsigned jj[LIST_SLOTS - 1];
+#pragma unroll
+                for (int k = 0; k < LIST_SLOTS - 1; ++k) jj[k] = min(v[k], (unsigned)N);
+                {
+                    const float4 o0 = s.link[jj[0]], o1 = s.link[jj[1]], o2 = s.link[jj[2]], o3 = s.link[jj[3]];
+                    D2D_LIST_PAIR(o0, jj[0]) D2D_LIST_PAIR(o1, jj[1]) D2D_LIST_PAIR(o2, jj[2]) D2D_LIST_PAIR(o3, jj[3])
+                    asm volatile("" ::"v"(o0.w), "v"(o1.w), "v"(o2.w), "v"(o3.w));       // .w kept live: ds_read_b128 (4 LDS cycles), not b96 (8)
+                }
+                if (__builtin_amdgcn_ballot_w64(v[4] != LIST_EMPTY) != 0ull) {
+                    const float4 o4 = s.link[jj[4]], o5 = s.link[jj[5]];
+                    D2D_LIST_PAIR(o4, jj[4]) D2D_LIST_PAIR(o5, jj[5])
+                    asm volatile("" ::"v"(o4.w), "v"(o5.w));
+                    if (__builtin_amdgcn_ballot_w64(v[6] != LIST_EMPTY) != 0ull) {
+                        const float4 o6 = s.link[jj[6]];
+                        D2D_LIST_PAIR(o6, jj[6])
+                        asm volatile("" ::"v"(o6.w));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < LIST_SLOTS - 1; ++k) {
+                    const unsigned j = v[k];
+                    if (j == LIST_EMPTY) break;
+                    const float4 o = s.link[j];
+                    D2D_LIST_PAIR(o, j)
+                }
+            }
+#undef D2D_LIST_PAIR
         } else if (LIKELY(use_masks)) {
             unsigned live = s.summ[rb];                                  // non-empty words of this RB, ascending
             const int iw = i >> 5;
@@ -531,6 +662,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                             else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                             if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                             acc = fmaf(o.z, g, acc);                     // simulator.py:97-101, linear mW
+                            asm volatile("" ::"v"(o.w));                 // .w kept live: the tuple comes by ds_read_b128 (4 LDS cycles), not b96 (8)
                         }
                         if (!more) break;
                         live &= live - 1u;
@@ -639,7 +771,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             // were published by the barrier before this pass, so no further synchronisation is needed here.
             if (UNLIKELY(type != LINK_SIDELINK && cap <= a.reward_param)) {
                 bool hit = false;
-                if (use_masks) {
+                if (LISTS && use_lists) {
+                    const unsigned short* mem = reinterpret_cast<const unsigned short*>(s.slots) + (unsigned)rb * LIST_SLOTS;
+                    for (int k = 0; k < LIST_SLOTS; ++k) {
+                        const unsigned j = mem[k];
+                        if (j != LIST_EMPTY && j != (unsigned)i) hit |= ((a.side_words[j >> 5] >> (j & 31u)) & 1u) != 0u;
+                    }
+                } else if (use_masks) {
                     for (int w = 0; w < W; ++w)
                         hit |= (s.mask[(unsigned)w * (unsigned)R + (unsigned)rb] & a.side_words[w]) != 0u;
                 } else {
@@ -861,13 +999,14 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     hipError_t err = hipSuccess;
     const int lpt = a.lpt;
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
+    const bool lists = a.walk == 2 && lpt > 0 && a.reward_fn != 3;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
-                     a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
+                     (a.walk == 0 || a.walk == 2) && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
     // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
-                      a.rb_out != nullptr && a.walk == 0 && a.prefetch_envs > 0 && a.ablate == 0 && a.mask_words > 0 &&
+                      (a.walk == 0 || a.walk == 2) && a.prefetch_envs > 0 && a.ablate == 0 && a.mask_words > 0 &&
                       a.fuse_obs == 4 && a.obs_q_per_row > 0 && (unsigned)block_threads / a.obs_q_per_row >= 1u &&
                       (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
@@ -880,15 +1019,19 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
             err = hipGetLastError();                                                                     \
         }                                                                                                \
     } while (0)
+#define D2D_LAUNCH_L(M, L)                                                                               \
+    do {                                                                                                 \
+        if (lpt == 1 && full && hot) D2D_LAUNCH_1(M, 1, true, 1, L);                                     \
+        else if (lpt == 1 && !full && hot2) D2D_LAUNCH_1(M, 1, false, 2, L);                             \
+        else if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true, 0, L);                                       \
+        else if (lpt == 2) D2D_LAUNCH_1(M, 2, false, 0, L);                                              \
+        else if (lpt == 1 && full) D2D_LAUNCH_1(M, 1, true, 0, L);                                       \
+        else if (lpt == 1) D2D_LAUNCH_1(M, 1, false, 0, L);                                              \
+        else D2D_LAUNCH_1(M, 0, false, 0, false);                                                        \
+    } while (0)
 #define D2D_LAUNCH(M)                                                                                    \
     do {                                                                                                 \
-        if (lpt == 1 && full && hot) D2D_LAUNCH_1(M, 1, true, 1);                                        \
-        else if (lpt == 1 && !full && hot2) D2D_LAUNCH_1(M, 1, false, 2);                                \
-        else if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true);                                             \
-        else if (lpt == 2) D2D_LAUNCH_1(M, 2, false);                                                    \
-        else if (lpt == 1 && full) D2D_LAUNCH_1(M, 1, true);                                             \
-        else if (lpt == 1) D2D_LAUNCH_1(M, 1, false);                                                    \
-        else D2D_LAUNCH_1(M, 0, false);                                                                  \
+        if (lists) D2D_LAUNCH_L(M, true); else D2D_LAUNCH_L(M, false);                                   \
     } while (0)
     switch (mode) {
         case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;
@@ -897,6 +1040,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
         case PL_SHADOW: D2D_LAUNCH(PL_SHADOW); break;
     }
 #undef D2D_LAUNCH
+#undef D2D_LAUNCH_L
 #undef D2D_LAUNCH_1
     return err;
 }

@@ -163,6 +163,11 @@ int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode);
 /* 1 (default): same-RB interferers found through per-RB membership bitmasks in LDS
  * (Actions.get_actions_by_rb, actions.py:27-31).  0: masked all-pairs sweep.  Same results.        */
 int d2d_set_bucketing(d2d_handle* h, int32_t enabled);
+/* 1 (default): d2d_step writes the decoded (rb, tx power dBm) of every link to D2D_BUF_RB / D2D_BUF_PWR
+ * - the `rb` / `tx_pwr_dbm` entries of D2DEnv._info (d2d_env.py:108-109).  0: a rollout that knows its
+ * own actions skips those 8 bytes per link and step; the two buffers then keep their last contents.
+ * d2d_step_rb_pwr (the values are the caller's) and d2d_step_host (always exported) are not affected.  */
+int d2d_set_export_actions(d2d_handle* h, int32_t enabled);
 
 /* Launch-geometry knobs (performance only, results do not change).                                 */
 typedef enum d2d_tuning {
@@ -179,7 +184,10 @@ typedef enum d2d_tuning {
     D2D_TUNE_STEP_PREFETCH = 11,   /* software-prefetch distance of the action rows, in envs: -1 = auto (the envs
                                       resident on the chip at once), 0 = off                                    */
     D2D_TUNE_STEP_LPT = 12,        /* links per thread held in registers: 1, 2 (half the waves per env), -1 = auto    */
-    D2D_TUNE_STEP_WALK = 10,       /* mask walk loop shape: 0 nested (words / members), 1 flattened; -1 = auto */
+    D2D_TUNE_STEP_WALK = 10,       /* same-RB interferer search: 0 membership masks, nested walk (words / members),
+                                      1 masks, flattened walk, 2 per-RB member lists (sorted in registers by the
+                                      receiver; an env that puts more than 8 links on one RB falls back to the
+                                      masks inside the launch); -1 = auto                                     */
     D2D_TUNE_STEP_ABLATE = 9,      /* DIAGNOSTIC builds only (D2D_BUILD_DIAG=1), the one key that DOES change
                                       results: bit mask of kernel parts to skip (1 interferer walk, 2 mask
                                       build, 4 mask clear, 8 result stores, 16 table store, 32 rb/pwr stores,

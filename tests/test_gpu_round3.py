@@ -1,0 +1,250 @@
+"""GPU tests of the round-3 additions, through the C ABI: the per-RB member-list interferer search (D2D_TUNE_STEP_WALK = 2)
+is bit-identical to the mask walk and the all-pairs sweep for every path-loss mode, reward and launch geometry - list
+overflow (more than eight links on one RB) included; d2d_set_export_actions; obs_dtype."""
+import numpy as np
+import pytest
+
+from golden_util import rel_err
+from oracle import d2d_oracle as orc
+from sim_util import default_links, random_layout
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+OUTS = ('BUF_SINR_DB', 'BUF_SNR_DB', 'BUF_RATE_BPS', 'BUF_CAPACITY', 'BUF_REWARD', 'BUF_OBS_TABLE', 'BUF_RB', 'BUF_PWR',
+        'BUF_ENV_FLAGS')
+
+
+@pytest.fixture(scope='module')
+def native():
+    from gym_d2d_amd import _native
+    _native.load_library()
+    return _native
+
+
+def _batch(num_envs, rbs, cues, dues, seed, **cfg):
+    from gym_d2d_amd.simulator import Simulator
+    rng = np.random.default_rng(seed)
+    sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=num_envs, **cfg))
+    pos = random_layout(rng, num_envs, cues, dues)
+    sim.set_positions(pos)
+    sim.set_links(sim.default_link_keys())
+    p = sim.config.num_pwr_actions
+    raw = np.concatenate([rng.integers(0, rbs * p['cue'], (num_envs, cues)),
+                          rng.integers(0, rbs * p['due'], (num_envs, dues))], axis=1).astype(np.int32)
+    return sim, pos, raw
+
+
+def _snapshot(sim, native, with_obs=False):
+    out = {name: sim.fetch(getattr(native, name)).copy() for name in OUTS}
+    if with_obs:
+        out['BUF_OBS'] = sim.fetch(native.BUF_OBS).copy()
+    return out
+
+
+def _variants(native, h, fn):
+    """fn() once per interferer-search variant; returns {name: snapshot}."""
+    out = {}
+    for name, bucket, walk in (('mask_walk', True, 0), ('member_lists', True, 2), ('all_pairs', False, 0)):
+        h.set_bucketing(bucket)
+        h.set_tuning(native.TUNE_STEP_WALK, walk)
+        out[name] = fn()
+    h.set_bucketing(True)
+    h.set_tuning(native.TUNE_STEP_WALK, -1)
+    return out
+
+
+def _same(snaps, ref_name='mask_walk'):
+    for name, snap in snaps.items():
+        for buf, ref in snaps[ref_name].items():
+            assert np.array_equal(snap[buf], ref, equal_nan=True), (name, buf)
+
+
+# shapes: lists never overflow / a few envs overflow / every env overflows (25, 18 links per RB) / N > 512 (two links per
+# thread) / one link per RB / a single RB
+SHAPES = [(33, 25, 25, 25), (64, 256, 256, 256), (16, 4, 40, 60), (8, 7, 0, 130), (5, 300, 100, 91), (9, 1, 64, 64),
+          (6, 64, 300, 400), (3, 500, 600, 600)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('reward', [0, 1, 2, 3])
+def test_member_lists_are_bit_identical_to_masks_and_all_pairs(native, shape, reward):
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(b, rbs, cues, dues, seed=sum(shape) + reward)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+    h.set_reward(reward, {0: 0.0, 1: 0.0, 2: -70.0, 3: 0.0}[reward])
+
+    if reward == 0:
+        h.upload(native.BUF_REWARD, np.zeros((b, cues + dues), np.float32))      # not written without a reward function
+
+    def run():
+        sim.step_arrays(raw)
+        return _snapshot(sim, native)
+    snaps = _variants(native, h, run)
+    _same(snaps)
+    tx, rx, ty = default_links(cues, dues)
+    ref = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(*orc.device_configs(cues, dues)[1:]),
+                        orc.PathLossSpec(), with_obs=False, chunk=8)
+    assert rel_err(snaps['member_lists']['BUF_SINR_DB'], ref['sinr_db']) <= TOL
+    assert rel_err(snaps['member_lists']['BUF_CAPACITY'], ref['capacity_mbps']) <= TOL
+    if reward == 1:
+        assert rel_err(snaps['member_lists']['BUF_REWARD'][:, 0], ref['reward']) <= TOL
+    sim.handle.close()
+
+
+def test_member_lists_with_skewed_actions_and_out_of_range_rbs(native):
+    """Action distributions a policy can produce: every DUE on one of 3 RBs (lists overflow in every env), exactly two links
+    per RB (no overflow anywhere), and envs with rb outside [0, R) (those links take the sweep, the others their lists)."""
+    b, rbs, cues, dues = 40, 64, 64, 64
+    sim, pos, raw = _batch(b, rbs, cues, dues, seed=77)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+    h.set_reward(1, 0.0)
+    p = sim.config.num_pwr_actions
+    rng = np.random.default_rng(3)
+    raw[:10, cues:] = rng.integers(0, 3, (10, dues)) * p['due'] + rng.integers(0, p['due'], (10, dues))
+    raw[10:20, :cues] = np.arange(cues)[None] * p['cue'] + 5
+    raw[10:20, cues:] = np.arange(dues)[None] * p['due'] + 7
+    raw[20:25, 3] = rbs * p['cue'] + 11               # rb == R: out of range
+    raw[25:30, cues + 5] = -4                         # negative action: rb = -1 (Python floor)
+
+    def run():
+        sim.step_arrays(raw)
+        return _snapshot(sim, native)
+    snaps = _variants(native, h, run)
+    _same(snaps)
+    flags = snaps['member_lists']['BUF_ENV_FLAGS']
+    assert (flags[20:30] & native.FLAG_RB_OUT_OF_RANGE).all() and not (flags[:20] & native.FLAG_RB_OUT_OF_RANGE).any()
+    sim.handle.close()
+
+
+@pytest.mark.parametrize('model', ['ple35', 'cost_hata', 'table', 'shadowing'])
+def test_member_lists_every_path_loss_mode(native, model):
+    from gym_d2d_amd import path_loss as pl
+
+    class Ple35(pl.LogDistancePathLoss):
+        def __init__(self, carrier_freq_GHz):
+            super().__init__(carrier_freq_GHz, 3.5)
+
+    class Plugin(pl.PathLoss):                       # evaluated on the host -> [D, D] table route
+        def __call__(self, tx, rx):
+            return 30.0 + 31.0 * np.log10(tx.position.distance(rx.position)) - 0.5 * tx.tx_antenna_gain_dBi
+
+    cls = {'ple35': Ple35, 'cost_hata': pl.CostHataPathLoss, 'table': Plugin, 'shadowing': pl.ShadowingPathLoss}[model]
+    b, rbs, cues, dues = (12, 6, 20, 30) if model != 'table' else (1, 6, 20, 30)
+    sim, pos, raw = _batch(b, rbs, cues, dues, seed=5, path_loss_model=cls, **({'seed': 99} if model == 'shadowing' else {}))
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+    for reward in (1, 2):
+        h.set_reward(reward, {1: 0.0, 2: -70.0}[reward])
+
+        def run():
+            if model == 'shadowing':                # the draws are keyed by (seed, step): restart the stream per variant
+                sim._install_tables()
+            sim.step_arrays(raw)
+            return _snapshot(sim, native)
+        _same(_variants(native, h, run))
+    sim.handle.close()
+
+
+@pytest.mark.parametrize('shape', [(13, 25, 25, 25), (7, 5, 9, 10), (10, 3, 30, 37)])
+def test_member_lists_small_envs_sharing_a_workgroup_and_fused_obs(native, shape):
+    """Several envs per workgroup: an overflow in ONE env sends the whole workgroup through the mask fallback; the fused
+    LinearObs expansion rides on either path.  Traffic-model CUEs as in BASELINE config 2."""
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(b, rbs, cues, dues, seed=sum(shape))
+    h = sim.handle
+    h.set_obs_mode(native.OBS_LINEAR)
+    ref = None
+    for walk in (0, 2):
+        h.set_tuning(native.TUNE_STEP_WALK, walk)
+        for epw, fuse in ((1, 0), (2, 1), (4, 1), (0, -1)):
+            h.set_tuning(native.TUNE_STEP_ENVS_PER_WG, epw)
+            h.set_tuning(native.TUNE_STEP_FUSE_OBS, fuse)
+            h.upload(native.BUF_OBS, np.full((b, cues + dues, 6 * (cues + dues)), np.nan, np.float32))
+            sim.step_arrays(raw)
+            snap = _snapshot(sim, native, True)
+            ref = ref or snap
+            for buf, r in ref.items():
+                assert np.array_equal(snap[buf], r, equal_nan=True), (walk, epw, fuse, buf)
+    sim.handle.close()
+
+
+def test_baseline_config_2_rollout_kernel_with_member_lists(native):
+    """The level-2 rollout specialisation (traffic-model prefix, fused 16-byte expansion) on lists vs masks, 1024 x 50."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    b, c, p, r = 1024, 25, 25, 25
+    snaps = {}
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, r * 21, (3, b, p)).astype(np.int32)
+    for walk in (0, 2):
+        env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p}, num_envs=b, cue_actions='traffic')
+        env.simulator.handle.set_tuning(native.TUNE_STEP_WALK, walk)
+        env.reset(seed=2024)
+        outs = []
+        for k in range(3):
+            obs, rew, _, info = env.step(torch.as_tensor(acts[k], device=env.device))
+            outs.append([obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), info['sinr_db'].cpu().numpy().copy(),
+                         info['rb'].cpu().numpy().copy()])
+        snaps[walk] = outs
+        env.close()
+    for k in range(3):
+        for x, y in zip(snaps[0][k], snaps[2][k]):
+            assert np.array_equal(x, y)
+
+
+def test_full_size_member_lists_against_masks(native):
+    """4096 x 512 (BASELINE config 3), the rollout specialisation: lists vs masks, every output of every env; about 6 % of
+    the envs overflow a list under uniformly random actions."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    from gym_d2d_amd.envs.obs_fn import OwnLinkObsFunction
+    b, c, p, r = 4096, 256, 256, 256
+    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
+    env.reset(seed=11)
+    h = env.simulator.handle
+    g = torch.Generator(device=env.device); g.manual_seed(4)
+    act = torch.randint(0, r * 21, (b, c + p), generator=g, device=env.device, dtype=torch.int32)
+    names = ('sinr_db', 'snr_db', 'rate_bps', 'capacity_mbps', 'reward', 'table', 'rb', 'pwr', 'env_flags')
+    got = {}
+    for walk in (0, 2):
+        h.set_tuning(native.TUNE_STEP_WALK, walk)
+        env.step(act)
+        torch.cuda.synchronize()
+        got[walk] = {n: env._t[n].clone() for n in names}
+    for n in names:
+        assert torch.equal(got[0][n], got[2][n]), n
+    # how many envs overflowed: count RBs with more than 8 links
+    rb = got[2]['rb'].long()
+    counts = torch.zeros((b, r), dtype=torch.long, device=env.device).scatter_add_(1, rb, torch.ones_like(rb))
+    over = int((counts.max(dim=1).values > 8).sum())
+    assert 0 < over < b // 4, over
+    env.close()
+
+
+def test_export_actions_switch(native):
+    """d2d_set_export_actions(0): D2D_BUF_RB / PWR keep their last contents, every other output is unchanged."""
+    sim, pos, raw = _batch(16, 32, 48, 48, seed=9)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+    sim.step_arrays(raw)
+    ref = _snapshot(sim, native)
+    marker = np.full_like(ref['BUF_RB'], -123)
+    for walk in (0, 2):
+        h.set_tuning(native.TUNE_STEP_WALK, walk)
+        h.upload(native.BUF_RB, marker); h.upload(native.BUF_PWR, marker)
+        h.set_export_actions(False)
+        sim.step_arrays(raw)
+        snap = _snapshot(sim, native)
+        assert (snap['BUF_RB'] == -123).all() and (snap['BUF_PWR'] == -123).all()
+        for buf in OUTS:
+            if buf not in ('BUF_RB', 'BUF_PWR'):
+                assert np.array_equal(snap[buf], ref[buf]), buf
+        h.set_export_actions(True)
+        sim.step_arrays(raw)
+        snap = _snapshot(sim, native)
+        for buf in OUTS:
+            assert np.array_equal(snap[buf], ref[buf]), buf
+    sim.handle.close()

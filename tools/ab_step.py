@@ -62,7 +62,15 @@ def stress(args):
     env.reset(seed=1)
     h = env.simulator.handle
     act = torch.randint(0, r * 21, (64, b, c + p), device=env.device, dtype=torch.int32)      # fresh actions per launch
-    variants = [(rw, name) for rw in (1, 0, 2, 3) for name in ('mask_walk_nested', 'mask_walk_flat', 'all_pairs')]
+    # (reward fn, search variant, decoded rb / pwr exported).  'two_per_rb' runs the lists on actions that put exactly two
+    # links on every RB: no list ever overflows, no lane of a wave has more members than another
+    variants = [(rw, name, ex) for rw in ((1, 0, 2) if args.quick else (1, 0, 2, 3))
+                for name in ('mask_walk_nested', 'member_lists') + (() if args.quick else ('mask_walk_flat', 'all_pairs'))
+                for ex in ((1, 0) if rw == 1 and name in ('mask_walk_nested', 'member_lists') else (1,))]
+    variants += [(1, 'member_lists_two_per_rb', 1), (1, 'mask_walk_two_per_rb', 1)]
+    pc, pd = env.num_pwr_actions['cue'], env.num_pwr_actions['due']
+    two = torch.cat([torch.arange(c, device=env.device, dtype=torch.int32) * pc + 3,
+                     torch.arange(p, device=env.device, dtype=torch.int32) * pd + 5])[None, None].expand(64, b, c + p).contiguous()
     times = {v: [] for v in variants}
     for rnd in range(args.rounds):
         for v in variants:
@@ -70,12 +78,14 @@ def stress(args):
                 continue
             h.set_reward(v[0], {0: 0.0, 1: 0.0, 2: -70.0, 3: 0.0}[v[0]])
             h.set_bucketing(v[1] != 'all_pairs')
-            h.set_tuning(_native.TUNE_STEP_WALK, 1 if v[1] == 'mask_walk_flat' else 0)
-            times[v].append(timed(h, act, 32 if v[1] != 'all_pairs' else 8))
+            h.set_export_actions(bool(v[2]))
+            h.set_tuning(_native.TUNE_STEP_WALK, 1 if v[1] == 'mask_walk_flat' else (2 if v[1].startswith('member_lists') else 0))
+            times[v].append(timed(h, two if v[1].endswith('two_per_rb') else act, 32 if v[1] != 'all_pairs' else 8))
+    h.set_export_actions(True)
     bytes_per = b * (c + p) * 64.0
     for v in variants:
         med = statistics.median(times[v])
-        emit({'sweep': 'stress_table_mode', 'reward_fn': v[0], 'variant': v[1], 'median_us': round(med, 2),
+        emit({'sweep': 'stress_table_mode', 'reward_fn': v[0], 'variant': v[1], 'export_rb_pwr': v[2], 'median_us': round(med, 2),
               'min_us': round(min(times[v]), 2), 'algorithmic_GBps': round(bytes_per / med / 1e3), 'rounds': len(times[v])},
              args.out)
     env.close()
@@ -141,13 +151,17 @@ def wall(args):
     env.reset(seed=1)
     h = env.simulator.handle
     acts = torch.randint(0, r * 21, (64, b, p), device=env.device, dtype=torch.int32)
-    variants = [(epw, fuse, blk) for fuse in (1, 0) for epw in (0, 1, 2, 4) for blk in ((0, 512) if fuse else (0,))]
+    variants = [(epw, fuse, blk, 0) for fuse in (1, 0) for epw in (0, 1, 2, 4) for blk in ((0, 512) if fuse else (0,))]
+    variants += [(0, 1, 0, 2), (2, 1, 0, 2), (0, 0, 0, 2)]           # member lists instead of the mask walk
+    if args.quick:
+        variants = [(0, 1, 0, 0), (0, 1, 0, 2), (0, 0, 0, 0), (0, 0, 0, 2)]
     times = {v: [] for v in variants}
     for rnd in range(args.rounds):
         for v in variants:
             h.set_tuning(_native.TUNE_STEP_ENVS_PER_WG, v[0])
             h.set_tuning(_native.TUNE_STEP_FUSE_OBS, v[1])
             h.set_tuning(_native.TUNE_STEP_BLOCK, v[2])
+            h.set_tuning(_native.TUNE_STEP_WALK, v[3])
             for k in range(20):
                 h.step(acts[k % 64].data_ptr())
             torch.cuda.synchronize()
@@ -158,7 +172,7 @@ def wall(args):
             times[v].append((time.perf_counter() - t0) / 500 * 1e6)
     for v in variants:
         med = statistics.median(times[v])
-        emit({'sweep': 'default_wall_per_step', 'envs_per_wg': v[0], 'fuse_obs': v[1], 'block': v[2],
+        emit({'sweep': 'default_wall_per_step', 'envs_per_wg': v[0], 'fuse_obs': v[1], 'block': v[2], 'walk': v[3],
               'wall_us_per_step': round(med, 2), 'agent_steps_per_s': round(b * (c + p) / med * 1e6)}, args.out)
     env.close()
 
@@ -167,6 +181,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('what', choices=['stress', 'default', 'wall', 'ablate'])
     ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--quick', action='store_true', help='stress: only the mask walk and the member lists')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
     {'stress': stress, 'default': default, 'wall': wall, 'ablate': ablate}[a.what](a)
