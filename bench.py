@@ -241,6 +241,9 @@ class _StubHandle:
     def set_obs_mode(self, m):
         pass
 
+    def set_export_actions(self, on):
+        pass
+
 
 class _StubEnv:
     def __init__(self, torch, b, n, first_env):
@@ -274,17 +277,214 @@ def parse_args(argv=None):
                     help="who drives the CUE links (default: the workload's own choice)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the per-step all-gather')
+    ap.add_argument('--gather', default='table', choices=['table', 'rewards'],
+                    help="N > 1: what the per-step all-gather carries (StepGatherer mode): rewards + the (sinr, snr) columns of the "
+                         "obs table, or rewards only")
+    ap.add_argument('--signal-every', type=int, default=1, help='N > 1, --gather table: the (sinr, snr) columns travel on every K-th step')
     ap.add_argument('--with-reset', action='store_true', help='redraw all device positions every 10 steps (device-side reset)')
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
     ap.add_argument('--no-single-env-latency', action='store_true',
                     help='N = 1 also times the drop-in single-env D2DEnv.step (host dicts in / out); this skips it')
-    ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,fuse')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='N = 1, default run: skip other_workloads / vec_env_step_ms / the write-ceiling probe (the headline only)')
+    ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,fuse,walk')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST HOOK: no GPU, gloo backend, synthetic per-rank results - exercises only the launcher / gather plumbing')
     ap.add_argument('--share-gpu', action='store_true',
                     help='TEST HOOK: every rank uses cuda:0 and gloo carries the collectives (RCCL refuses two ranks on one '
                          'GPU) - the real worker with N > 1 on a one-GPU box; never a measurement')
     return ap.parse_args(argv)
+
+
+GROUP = 20          # launches per HIP-event pair when a step is a single kernel
+CORE_BYTES = 40.0   # action 4 + positions 16 + outputs 16 + reward 4, per agent-step
+
+
+def algorithmic_bytes(n, obs):
+    """Per agent-step: the 40 core bytes + 24 N for the materialised LinearObs (+ the 24 the expansion
+    reads) or + 24 for the compact table."""
+    return CORE_BYTES + (24.0 * n if obs == 'linear' else (24.0 if obs == 'table' else 0.0))
+
+
+class Session:
+    """One workload on this rank's GPU: the env, its pre-generated actions and the timing loops."""
+
+    def __init__(self, torch, args, key, obs, dev, rank, local, steps, warmup, *, envs=0, cue_mode='', tune='', stub=False,
+                 export=True):
+        self.torch, self.args, self.key, self.obs, self.dev, self.rank, self.stub = torch, args, key, obs, dev, rank, stub
+        w = dict(WORKLOADS[key])
+        if envs:
+            w['envs'] = envs
+        self.w = w
+        b, c, p, r = w['envs'], w['cues'], w['dues'], w['rbs']
+        self.b, self.c, self.p, self.r, self.n = b, c, p, r, c + p
+        if w.get('plugin') and obs == 'linear':
+            self.obs = obs = 'table'
+        self.cue_mode = cue_mode or ('traffic' if w.get('traffic') else 'agent')
+        self.steps, self.warmup, self.total = steps, warmup, steps + warmup
+        if stub:
+            self.env = _StubEnv(torch, b, self.n, rank * b)
+            self.h = self.env.simulator.handle
+            self.n_agents = self.n
+        else:
+            from gym_d2d_amd import _native
+            from gym_d2d_amd.envs import VecD2DEnv
+            from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
+            self.native = _native
+            cfg = {'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': local,
+                   'obs_fn': LinearObsFunction if obs == 'linear' else OwnLinkObsFunction}
+            if w.get('plugin'):
+                from gym_d2d_amd.path_loss import FreeSpacePathLoss
+                cfg['path_loss_model'] = FreeSpacePathLoss
+            self.env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b, cue_actions=self.cue_mode, export_actions=export)
+            self.h = h = self.env.simulator.handle
+            self.n_agents = self.env.num_agents
+            if obs == 'none':
+                h.set_obs_mode(_native.OBS_NONE)
+            tune_keys = {'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
+                         'xcd': _native.TUNE_OBS_XCD_REMAP, 'block': _native.TUNE_OBS_BLOCK,
+                         'threads': _native.TUNE_STEP_THREADS, 'epw': _native.TUNE_STEP_ENVS_PER_WG,
+                         'sblock': _native.TUNE_STEP_BLOCK, 'fuse': _native.TUNE_STEP_FUSE_OBS, 'walk': _native.TUNE_STEP_WALK}
+            for kv in filter(None, tune.split(',')):
+                k, v = kv.split('=')
+                if k == 'bucket':
+                    h.set_bucketing(bool(int(v)))
+                else:
+                    h.set_tuning(tune_keys[k], int(v))
+            self.env.reset(seed=1234)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        pc, pd = self.env.num_pwr_actions['cue'], self.env.num_pwr_actions['due']
+        # actions of the links the AGENTS drive: [total, B, C+P], or DUE-only [total, B, P] when the CUEs follow the traffic model
+        self.actions = torch.empty((self.total, b, self.n_agents), dtype=torch.int32, device=dev)
+        if self.n_agents == self.n and c:
+            self.actions[:, :, :c] = torch.randint(0, r * pc, (self.total, b, c), generator=g, device=dev, dtype=torch.int32)
+        if p:
+            self.actions[:, :, self.n_agents - p:] = torch.randint(0, r * pd, (self.total, b, p), generator=g, device=dev, dtype=torch.int32)
+        # An event pair around ONE launch adds about 3-6 us to what it measures (tools/probes/launch_floor.hip) and costs host
+        # time per step: irrelevant beside the 3.7 ms obs kernel, 10-30 % of a 17-40 us step.  So: two kernels per step with
+        # the expansion dominant (LinearObs, N > 128) -> per-launch events inside the timed region.  One kernel per step
+        # (compact table, or small N with the expansion fused) -> the timed region runs without events, and a second pass
+        # over the same steps brackets GROUPS of back-to-back launches with one event pair (on the stream the kernels run
+        # on): average launch duration = group time / launches, inter-launch gaps included.
+        self.events_in_timed = self.obs == 'linear' and self.n > 128
+
+    def run(self, k0, k1, gatherer=None, with_reset=False):
+        h, env, actions = self.h, self.env, self.actions
+        for k in range(k0, k1):
+            new_episode = with_reset and k % 10 == 0
+            if new_episode:                              # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
+                h.reset_positions(1234, k // 10)
+            h.step(actions[k].data_ptr())
+            if gatherer is not None and (new_episode or k == 0):
+                gatherer.gather_positions(env._t['table'])      # position columns only change at reset (not per step)
+            if gatherer is not None:
+                gatherer.launch(env._t['reward'], env._t['table'])
+        if gatherer is not None:
+            gatherer.wait()
+
+    def timed(self, fence, gatherer=None, with_reset=False):
+        """W untimed steps, then exactly K steps between two fences (barrier + device synchronise on both sides)."""
+        torch, h = self.torch, self.h
+        self.run(0, self.warmup, gatherer, with_reset)
+        fence()
+        if gatherer is not None:
+            gatherer.reset_timing()
+        h.profile_reset()
+        h.profile_enable(self.events_in_timed)
+        t0 = time.perf_counter()
+        self.run(self.warmup, self.total, gatherer, with_reset)
+        fence()
+        dt = time.perf_counter() - t0
+        step_ms, step_n = h.profile_read(0)
+        obs_ms, obs_n = h.profile_read(1)
+        h.profile_enable(False)
+        if not self.events_in_timed and not self.stub:
+            stream = torch.cuda.current_stream(self.dev)          # VecD2DEnv runs the library's kernels on this stream
+            pairs = []
+            for k0 in range(self.warmup, self.total, GROUP):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                k1 = min(k0 + GROUP, self.total)
+                e0.record(stream)
+                for k in range(k0, k1):
+                    h.step(self.actions[k].data_ptr())
+                e1.record(stream)
+                pairs.append((e0, e1, k1 - k0))
+            torch.cuda.synchronize(self.dev)
+            step_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in pairs)
+            step_n = sum(c for _, _, c in pairs)
+            obs_ms, obs_n = 0.0, 0
+        return {'dt': dt, 'step_ms': step_ms, 'step_n': step_n, 'obs_ms': obs_ms, 'obs_n': obs_n}
+
+    def roofline(self, t):
+        """The dominant kernel's block: algorithmic bytes per launch / its average launch duration (HIP events)."""
+        b, n = self.b, self.n
+        fused = self.obs == 'linear' and not self.events_in_timed   # small N: the expansion runs inside the step launch
+        if fused:
+            per_launch = b * n * (CORE_BYTES + 24.0 * n)
+            avg_ms = t['step_ms'] / max(t['step_n'], 1)
+            roof = {'kernel': 'step_kernel (LinearObs expansion fused)'}
+        elif self.obs == 'linear' and t['obs_n']:
+            # dominant kernel: obs expansion.  Algorithmic bytes per launch = B*N*(24N written + 24 read of T)
+            per_launch = b * n * (24.0 * n + 24.0)
+            avg_ms = t['obs_ms'] / t['obs_n']
+            roof = {'kernel': 'obs_expand_kernel'}
+        else:
+            per_launch = b * n * algorithmic_bytes(n, self.obs)
+            avg_ms = t['step_ms'] / max(t['step_n'], 1)
+            roof = {'kernel': 'step_kernel'}
+        ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roof.update({'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                     'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': per_launch, 'traffic': None,
+                     'timing': ('HIP events around every launch on the library stream, inside the timed region' if self.events_in_timed
+                                else f'HIP events around groups of {GROUP} back-to-back launches (one kernel per step) on the '
+                                     'library stream, in a second pass over the same steps; the timed region itself runs '
+                                     'without events')})
+        if not self.stub:
+            attach_traffic(roof, self.key, self.obs, bool(self.args.envs))
+        return roof
+
+    def config(self, world, gather_desc=''):
+        w = self.w
+        return {'workload': w['name'], 'envs_per_gpu': self.b, 'links_per_env': self.n, 'obs_mode': self.obs,
+                'reward_fn': 'SystemCapacity',
+                'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else 'LogDistance(ple=2)',
+                'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
+                'cue_actions': self.cue_mode + (' (UplinkTrafficModel round-robin, held in the kernel\'s link records; agents supply DUE actions only)'
+                                                if self.cue_mode == 'traffic' else ' (agents supply CUE and DUE actions)'),
+                'parallelism': f'env-shard x{world}' + gather_desc}
+
+    def vec_env_step_ms(self, steps=200):
+        """Wall time per VecD2DEnv.step - the PUBLIC batched API (obs, rewards, dones, info out), fresh actions every step,
+        nothing synchronised inside the loop - beside the bare C-ABI handle loop over the same steps."""
+        torch, env, h = self.torch, self.env, self.h
+        acts = [self.actions[k % self.total] for k in range(steps)]
+        out = {}
+        for name, fn in (('vec_env_step', lambda a: env.step(a)), ('handle_step', lambda a: h.step(a.data_ptr()))):
+            for a in acts[:10]:
+                fn(a)
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for a in acts:
+                fn(a)
+            host = time.perf_counter() - t0               # the loop's own (host) time: what the Python wrapper costs
+            torch.cuda.synchronize(self.dev)
+            out[name + '_ms'] = (time.perf_counter() - t0) / steps * 1e3
+            out[name + '_host_ms'] = host / steps * 1e3
+        return out
+
+    def close(self):
+        self.env.close()
+        self.actions = None
+
+
+def summarise(sess, t, steps, world=1):
+    """A workload's entry under other_workloads / core_mode: throughput, ms per step and the roofline block."""
+    return {'workload': sess.w['name'], 'obs_mode': sess.obs, 'cue_actions': sess.cue_mode, 'steps': steps,
+            'value': sess.b * sess.n * steps * world / t['dt'], 'unit': 'agent-steps/s', 'ms_per_step': t['dt'] / steps * 1e3,
+            'algorithmic_bytes_per_agent_step': algorithmic_bytes(sess.n, sess.obs) if not (sess.obs == 'linear' and sess.n > 128)
+            else 40.0 + 24.0 * sess.n,
+            'roofline': sess.roofline(t)}
 
 
 def worker(args):
@@ -297,12 +497,10 @@ def worker(args):
     if os.environ.get('D2D_BENCH_TEST_FAIL_RANK') == str(rank):       # test hook: a rank that dies must fail the job
         raise SystemExit(3)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    stub = args.stub_cpu
     w = dict(WORKLOADS[args.workload])
     if args.envs:
         w['envs'] = args.envs
-    b, c, p, r = w['envs'], w['cues'], w['dues'], w['rbs']
-    n = c + p
-    stub = args.stub_cpu
 
     # the CPU baseline runs first: this process has not initialised HIP yet, so its fork()ed pool is safe
     cpu = None
@@ -327,7 +525,10 @@ def worker(args):
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
+        if 'MASTER_PORT' not in os.environ:
+            if world > 1:
+                raise SystemExit('MASTER_PORT is not set: launch the ranks through `python bench.py --gpus N` or torch.distributed.run')
+            os.environ['MASTER_PORT'] = str(_free_port())          # one rank (--force-dist): any free port will do
         if stub or args.share_gpu:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
@@ -335,82 +536,12 @@ def worker(args):
 
     # the path every existing gym-d2d user calls: one env, dicts in / out (d2d_env.py:62-71).  Reported beside the batch
     # number, never as `value`; timed before the batch env exists so its 26 GB of buffers are not in the picture.
+    c, p, r = w['cues'], w['dues'], w['rbs']
     single_ms = None
     if rank == 0 and world == 1 and not args.no_single_env_latency and not stub:
         single_ms = {'25 CUE + 25 DUE pairs, 25 RB (reference default env)': single_env_latency(25, 25, 25, local)}
         if (c, p, r) != (25, 25, 25):
             single_ms[f'{c} CUE + {p} DUE pairs, {r} RB'] = single_env_latency(c, p, r, local)
-
-    if w.get('plugin'):
-        args.obs = 'table'
-    cue_mode = args.cue_actions or ('traffic' if w.get('traffic') else 'agent')
-    if stub:
-        env = _StubEnv(torch, b, n, rank * b)
-        h = env.simulator.handle
-        n_agents = n
-    else:
-        from gym_d2d_amd import _native
-        from gym_d2d_amd.envs import VecD2DEnv
-        from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
-        cfg = {'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': local,
-               'obs_fn': LinearObsFunction if args.obs == 'linear' else OwnLinkObsFunction}
-        if w.get('plugin'):
-            from gym_d2d_amd.path_loss import FreeSpacePathLoss
-            cfg['path_loss_model'] = FreeSpacePathLoss
-        env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b, cue_actions=cue_mode)
-        h = env.simulator.handle
-        n_agents = env.num_agents
-        if args.obs == 'none':
-            h.set_obs_mode(_native.OBS_NONE)
-        tune_keys = {'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
-                     'xcd': _native.TUNE_OBS_XCD_REMAP, 'block': _native.TUNE_OBS_BLOCK,
-                     'threads': _native.TUNE_STEP_THREADS, 'epw': _native.TUNE_STEP_ENVS_PER_WG,
-                     'sblock': _native.TUNE_STEP_BLOCK, 'fuse': _native.TUNE_STEP_FUSE_OBS}
-        for kv in filter(None, args.tune.split(',')):
-            k, v = kv.split('=')
-            if k == 'bucket':
-                h.set_bucketing(bool(int(v)))
-            else:
-                h.set_tuning(tune_keys[k], int(v))
-        env.reset(seed=1234)
-
-    total = args.steps + args.warmup
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    pc, pd = env.num_pwr_actions['cue'], env.num_pwr_actions['due']
-    # actions of the links the AGENTS drive: [total, B, C+P], or DUE-only [total, B, P] when the CUEs follow the traffic model
-    actions = torch.empty((total, b, n_agents), dtype=torch.int32, device=dev)
-    if n_agents == n and c:
-        actions[:, :, :c] = torch.randint(0, r * pc, (total, b, c), generator=g, device=dev, dtype=torch.int32)
-    if p:
-        actions[:, :, n_agents - p:] = torch.randint(0, r * pd, (total, b, p), generator=g, device=dev, dtype=torch.int32)
-
-    gatherer = None
-    if use_dist and not args.no_gather:
-        from gym_d2d_amd.distributed import StepGatherer
-        gatherer = StepGatherer(b, n, dev)
-
-    # An event pair around ONE launch adds about 3-6 us to what it measures (tools/probes/launch_floor.hip: a single
-    # empty wave reads 6 us) and costs host time per step: irrelevant beside the 3.7 ms obs kernel, 10-30 % of a 17-40 us
-    # step.  So: two kernels per step with the expansion dominant (LinearObs, N > 128) -> per-launch events inside the
-    # timed region.  One kernel per step (compact table, or small N with the expansion fused) -> the timed region runs
-    # without events, and a second pass over the same steps brackets GROUPS of back-to-back launches with one event pair
-    # (on the stream the kernels run on): average launch duration = group time / launches, inter-launch gaps included.
-    events_in_timed = args.obs == 'linear' and n > 128
-    GROUP = 20
-
-    def run(k0, k1):
-        for k in range(k0, k1):
-            new_episode = args.with_reset and k % 10 == 0
-            if new_episode:                              # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
-                h.reset_positions(1234, k // 10)
-            h.step(actions[k].data_ptr())
-            if gatherer is not None and (new_episode or k == 0):
-                gatherer.gather_positions(env._t['table'])      # position columns only change at reset (not per step)
-            if gatherer is not None:
-                gatherer.launch(env._t['reward'], env._t['table'])
-        if gatherer is not None:
-            gatherer.wait()
 
     def fence():
         if not stub:
@@ -420,74 +551,25 @@ def worker(args):
         if not stub:
             torch.cuda.synchronize(dev)
 
-    run(0, args.warmup)
-    fence()
-    h.profile_reset()
-    h.profile_enable(events_in_timed)
-    t0 = time.perf_counter()
-    run(args.warmup, total)
-    fence()
-    dt = time.perf_counter() - t0
-    step_ms, step_n = h.profile_read(0)
-    obs_ms, obs_n = h.profile_read(1)
-    h.profile_enable(False)
-    if not events_in_timed and not stub:
-        stream = torch.cuda.current_stream(dev)          # VecD2DEnv runs the library's kernels on this stream
-        pairs = []
-        for k0 in range(args.warmup, total, GROUP):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            k1 = min(k0 + GROUP, total)
-            e0.record(stream)
-            for k in range(k0, k1):
-                h.step(actions[k].data_ptr())
-            e1.record(stream)
-            pairs.append((e0, e1, k1 - k0))
-        torch.cuda.synchronize(dev)
-        step_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in pairs)
-        step_n = sum(c for _, _, c in pairs)
-        obs_ms, obs_n = 0.0, 0
-    flags = env.status_flags()
+    sess = Session(torch, args, args.workload, args.obs, dev, rank, local, args.steps, args.warmup, envs=args.envs,
+                   cue_mode=args.cue_actions, tune=args.tune, stub=stub)
+    b, n = sess.b, sess.n
 
-    # SURVEY.md 8(d): report the 'core' mode beside the with-obs mode.  Same envs, same actions, obs_fn swapped for the
-    # compact table (what a learner that builds its own features consumes): the step is then the step kernel alone.
-    core = None
-    if world == 1 and rank == 0 and not stub and args.obs == 'linear' and n > 128:
-        h.set_obs_mode(_native.OBS_TABLE)
-        for k in range(args.warmup):
-            h.step(actions[k].data_ptr())
-        torch.cuda.synchronize(dev)
-        t0c = time.perf_counter()
-        for k in range(args.warmup, total):
-            h.step(actions[k].data_ptr())
-        torch.cuda.synchronize(dev)
-        dtc = time.perf_counter() - t0c
-        stream = torch.cuda.current_stream(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for k in range(args.warmup, total):
-            h.step(actions[k].data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        k_ms = e0.elapsed_time(e1) / args.steps
-        h.set_obs_mode(_native.OBS_LINEAR)
-        core_bytes_launch = b * n * 64.0
-        core = {'obs_mode': 'table (compact [B, N, 6] obs, no LinearObs expansion)', 'value': b * n * args.steps / dtc,
-                'unit': 'agent-steps/s', 'ms_per_step': dtc / args.steps * 1e3,
-                'roofline': {'kernel': 'step_kernel', 'bound': 'hbm', 'achieved': core_bytes_launch / (k_ms * 1e-3) / 1e9,
-                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': core_bytes_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             'avg_launch_ms': k_ms, 'algorithmic_bytes_per_launch': core_bytes_launch,
-                             'timing': f'one HIP event pair around {args.steps} back-to-back launches'}}
+    def make_gatherer(mode, signal_every=1):
+        from gym_d2d_amd.distributed import StepGatherer
+        return StepGatherer(b, n, dev, mode=mode, signal_every=signal_every, timing=not stub)
 
+    gatherer = make_gatherer(args.gather, args.signal_every) if use_dist and not args.no_gather else None
+    t = sess.timed(fence, gatherer, args.with_reset)
+    flags = sess.env.status_flags()
+    gather_ms = gatherer.gather_ms() if gatherer is not None else None
+    # evidence that the collective saw every rank: a count all-reduce, and the last step's rewards summed two ways
+    # (all-reduce of the local sums vs the sum of what the all-gather delivered)
     dist_info = {}
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # evidence that the collective saw every rank: a count all-reduce, and the last step's rewards summed two ways
-        # (all-reduce of the local sums vs the sum of what the all-gather delivered)
         ones = torch.ones(1, device=dev, dtype=torch.float64)
         dist.all_reduce(ones)
-        local_sum = env._t['reward'][:, 0].double().sum().reshape(1)
+        local_sum = sess.env._t['reward'][:, 0].double().sum().reshape(1)
         dist.all_reduce(local_sum)
         dist_info = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
                      'allreduce_rank_count': float(ones.item()), 'allreduce_reward_checksum': float(local_sum.item())}
@@ -498,54 +580,76 @@ def worker(args):
             dist_info['allgather_envs'] = int(all_reward.numel())
             dist_info['checksums_agree'] = bool(abs(gsum - dist_info['allreduce_reward_checksum'])
                                                 <= 1e-6 * max(1.0, abs(gsum)))
+    # what the gather costs the step loop: the same steps again without it
+    t_nogather = sess.timed(fence, None, args.with_reset) if gatherer is not None else None
+
+    # SURVEY.md 8(d): report the 'core' mode beside the with-obs mode.  Same envs, same actions, obs_fn swapped for the
+    # compact table (what a learner that builds its own features consumes): the step is then the step kernel alone.
+    # The decoded (rb, pwr) planes behind info['rb'] / info['tx_pwr_dbm'] are a rollout's own actions again: the entry is
+    # measured without them (d2d_set_export_actions(0), 64 algorithmic bytes per link) and, beside it, with them.
+    core = None
+    if not stub and sess.obs == 'linear' and n > 128 and (world == 1 or not args.no_gather):
+        core = core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer)
+
+    dt = t['dt']
+    if use_dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # every rank's own clock and kernels, rank-major
+        mine = torch.tensor([t['dt'] / args.steps * 1e3, t['step_ms'] / max(t['step_n'], 1), (t['obs_ms'] / t['obs_n']) if t['obs_n'] else 0.0,
+                             gather_ms or 0.0], device=dev, dtype=torch.float64)
+        every = torch.empty(world * 4, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.view(world, 4)
+        dist_info['per_rank'] = [{'rank': k, 'ms_per_step': float(row[0]), 'step_kernel_ms': float(row[1]),
+                                  'obs_expand_kernel_ms': float(row[2]) or None, 'gather_ms_per_step': float(row[3]) or None}
+                                 for k, row in enumerate(every.cpu())]
+        if gatherer is not None:
+            tn = torch.tensor([t_nogather['dt']], device=dev, dtype=torch.float64)
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            dist_info['gather'] = {
+                'mode': args.gather, 'signal_every': args.signal_every,
+                'bytes_per_gpu_per_step': gatherer.bytes_per_signal_launch if args.signal_every == 1 else
+                gatherer.bytes_per_launch + (gatherer.bytes_per_signal_launch - gatherer.bytes_per_launch) / args.signal_every,
+                'gather_ms_per_step': gather_ms,                                   # side-stream events, rank 0
+                'ms_per_step_without_gather': float(tn.item()) / args.steps * 1e3,  # max over ranks
+                'gather_exposed_ms': (dt - float(tn.item())) / args.steps * 1e3,    # what the step loop pays for it
+                'timing': 'HIP events on the gather side stream around (staging copies + all-gathers) of every launch; exposed = '
+                          'ms_per_step with the gather minus the same steps without it'}
+
+    extras = {}
+    if rank == 0 and world == 1 and not stub and not args.no_extras and args.workload == 'stress' and args.obs == 'linear' \
+            and not args.envs and not args.tune:
+        sess.close()
+        extras = n1_extras(torch, args, dev, local, fence)
 
     if rank == 0:
         agent_steps = b * n * args.steps * world
         value = agent_steps / dt
-        core_bytes = 40.0                      # action 4 + positions 16 + outputs 16 + reward 4
-        obs_bytes = 24.0 * n                   # LinearObs materialised: 6N floats per agent
-        fused = args.obs == 'linear' and not events_in_timed   # small N: the expansion runs inside the step launch
-        if fused:
-            per_launch = b * n * (core_bytes + obs_bytes)
-            avg_ms = step_ms / max(step_n, 1)
-            roof = {'kernel': 'step_kernel (LinearObs expansion fused)'}
-        elif args.obs == 'linear' and obs_n:
-            # dominant kernel: obs expansion.  Algorithmic bytes per launch = B*N*(24N written + 24 read of T)
-            per_launch = b * n * (obs_bytes + 24.0)
-            avg_ms = obs_ms / obs_n
-            roof = {'kernel': 'obs_expand_kernel'}
-        else:
-            per_launch = b * n * (core_bytes + (24.0 if args.obs == 'table' else 0.0))
-            avg_ms = step_ms / max(step_n, 1)
-            roof = {'kernel': 'step_kernel'}
-        ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        roof.update({'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                     'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': per_launch, 'traffic': None,
-                     'timing': ('HIP events around every launch on the library stream, inside the timed region' if events_in_timed
-                                else f'HIP events around groups of {GROUP} back-to-back launches (one kernel per step) on the '
-                                     'library stream, in a second pass over the same steps; the timed region itself runs '
-                                     'without events')})
-        if not stub:
-            attach_traffic(roof, args, w)
+        roof = sess.roofline(t)
+        if extras.get('box_write_ceiling'):
+            roof['box_ceiling_GBs'] = extras['box_write_ceiling']['GBps']
+            roof['frac_of_box_ceiling'] = roof['achieved'] / roof['box_ceiling_GBs'] if roof['kernel'] == 'obs_expand_kernel' else None
+            roof['box_ceiling_note'] = ('the best pure-store kernel this library could build on this box (box_write_ceiling); above 1 the obs '
+                                        'kernel out-writes every fill variant tried')
+        cfg = sess.config(world, (f' + per-step all-gather ({args.gather}: rewards' + (', (sinr, snr) columns of the obs table'
+                                  + (f' every {args.signal_every} steps' if args.signal_every > 1 else '') if args.gather == 'table' else '')
+                                  + '; position columns once per episode)') if gatherer else '')
+        cfg['positions'] = 'redrawn on the device every 10 steps' if args.with_reset else 'fixed over the run'
         out = {
             'metric': 'env agent-steps/sec (batch x agents)', 'value': value, 'unit': 'agent-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': w['name'], 'envs_per_gpu': b, 'links_per_env': n, 'obs_mode': args.obs,
-                       'reward_fn': 'SystemCapacity',
-                       'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else 'LogDistance(ple=2)',
-                       'positions': 'redrawn on the device every 10 steps' if args.with_reset else 'fixed over the run',
-                       'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
-                       'cue_actions': cue_mode + (' (UplinkTrafficModel round-robin, held in the kernel\'s link records; agents supply DUE actions only)'
-                                                  if cue_mode == 'traffic' else ' (agents supply CUE and DUE actions)'),
-                       'parallelism': f'env-shard x{world}' + (' + per-step all-gather(reward, sinr/snr columns of the obs table; position columns once per episode)'
-                                                                     if gatherer else '')},
+            'config': cfg,
             'roofline': roof,
-            'kernels': {'step_kernel_ms': step_ms / max(step_n, 1), 'obs_expand_kernel_ms': (obs_ms / obs_n) if obs_n else None},
-            'algorithmic_bytes_per_agent_step': core_bytes + (obs_bytes if args.obs == 'linear' else (24.0 if args.obs == 'table' else 0.0)),
+            'kernels': {'step_kernel_ms': t['step_ms'] / max(t['step_n'], 1), 'obs_expand_kernel_ms': (t['obs_ms'] / t['obs_n']) if t['obs_n'] else None},
+            'algorithmic_bytes_per_agent_step': algorithmic_bytes(n, sess.obs),
             'status_flags': flags,
             'target_agent_steps_per_s': 1e7,
         }
+        if world > 1 or args.force_dist:
+            out['value_per_gpu'] = value / world
         out.update(dist_info)
         if stub:
             out['stub'] = 'CPU plumbing test - not a measurement'
@@ -555,23 +659,100 @@ def worker(args):
             out['single_env_step_ms'] = single_ms
         if core is not None:
             out['core_mode'] = core
+        for k in ('other_workloads', 'vec_env_step_ms', 'box_write_ceiling'):
+            if k in extras:
+                out[k] = extras[k]
         if cpu is not None:
             out['cpu_baseline'] = cpu
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)                 # the real stdout is back for the one line that belongs there
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)                            # teardown chatter (RCCL / ROCm) goes to stderr again
-    env.close()
+    if sess.actions is not None:
+        sess.close()
     if use_dist:
         dist.destroy_process_group()
 
 
-def attach_traffic(roof, args, w):
+def core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer):
+    """The headline session's envs and actions stepped with the compact-table obs (no LinearObs expansion); with N > 1 the
+    per-step gather is the rewards-only plan (16 KB per GPU: a 16.8 MB ring all-gather would outlast the 30 us step ten times)."""
+    _native, h, b, n = sess.native, sess.h, sess.b, sess.n
+    h.set_obs_mode(_native.OBS_TABLE)
+    saved_obs, saved_events = sess.obs, sess.events_in_timed
+    sess.obs, sess.events_in_timed = 'table', False
+    out = {}
+    try:
+        for export in (False, True):
+            h.set_export_actions(export)
+            gatherer = make_gatherer('rewards') if use_dist else None
+            t = sess.timed(fence, gatherer)
+            dt = t['dt']
+            if use_dist:
+                import torch.distributed as dist
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            entry = {'obs_mode': 'table (compact [B, N, 6] obs, no LinearObs expansion)', 'value': b * n * args.steps * world / dt,
+                     'unit': 'agent-steps/s', 'ms_per_step': dt / args.steps * 1e3, 'roofline': sess.roofline(t)}
+            if gatherer is not None:
+                entry['gather'] = {'mode': 'rewards', 'bytes_per_gpu_per_step': gatherer.bytes_per_launch,
+                                   'gather_ms_per_step': gatherer.gather_ms()}
+            if not export:
+                entry['decoded_rb_pwr_export'] = ('off (d2d_set_export_actions(0)): info[rb] / info[tx_pwr_dbm] are the rollout\'s own '
+                                                  'actions; 64 algorithmic bytes per link and step')
+                out = entry
+            else:
+                out['with_decoded_rb_pwr_export'] = {k: entry[k] for k in ('value', 'ms_per_step', 'roofline')}
+    finally:
+        h.set_export_actions(True)
+        h.set_obs_mode(_native.OBS_LINEAR)
+        sess.obs, sess.events_in_timed = saved_obs, saved_events
+    return out
+
+
+def n1_extras(torch, args, dev, local, fence):
+    """Beside the headline, in the same driver-run line (never as `value`): BASELINE configs 2 and 4 and an episode loop with
+    the device-side reset, each with its own roofline block; the public VecD2DEnv.step against the bare handle loop; the
+    box's write ceiling."""
+    out = {'other_workloads': {}, 'vec_env_step_ms': {}}
+    # BASELINE.json configs[1]: 1024 x 50, traffic-model CUEs, LinearObs fused into the step launch
+    s = Session(torch, args, 'default', 'linear', dev, 0, local, 200, 20)
+    out['other_workloads']['default'] = summarise(s, s.timed(fence), 200)
+    out['vec_env_step_ms']['default (config 2), LinearObs'] = s.vec_env_step_ms()
+    s.close()
+    # BASELINE.json configs[3]: FreeSpacePathLoss + a custom ObsFunction through the plugin ABI, 4096 x 512
+    s = Session(torch, args, 'plugin', 'table', dev, 0, local, 200, 20)
+    out['other_workloads']['plugin'] = summarise(s, s.timed(fence), 200)
+    out['vec_env_step_ms']['stress sizes, compact obs (OwnLinkObsFunction)'] = s.vec_env_step_ms()
+    s.close()
+    # the stress workload as EPISODES: positions redrawn on the device every 10 steps (d2d_env.py:16,45-52), 3 episodes
+    s = Session(torch, args, 'stress', 'linear', dev, 0, local, 30, 10)
+    e = summarise(s, s.timed(fence, None, True), 30)
+    e['positions'] = 'redrawn on the device every 10 steps (reset_kernel inside the timed region), 3 episodes'
+    out['other_workloads']['stress_with_reset'] = e
+    # the write ceiling of THIS box: pure fill kernels in a family of store geometries that contains the obs kernel's own
+    try:
+        best, rates = s.h.probe_write_variants(8 << 30, 5)
+        blocks, rows = (768, 1024, 512, 256), (2, 4, 8, 32)
+        k = max(range(len(rates)), key=lambda v: rates[v])
+        name = 'hipMemsetAsync' if k == 32 else f'{blocks[k & 3]} threads x {rows[(k >> 2) & 3]} rows per workgroup, ' + ('plain' if k & 16 else 'nontemporal') + ' stores'
+        out['box_write_ceiling'] = {'GBps': best, 'best_variant': name, 'obs_kernel_geometry_GBps': rates[0], 'hipMemsetAsync_GBps': rates[32],
+                                    'what': 'd2d_probe_write_variants: 8 GiB written 5 times by each of 32 pure fill kernels (block 768 / 1024 / 512 / 256 '
+                                            'threads x 2 / 4 / 8 / 32 rows per workgroup x nontemporal / plain 16-byte stores, XCD-grouped dispatch '
+                                            'order; the first is the obs kernel\'s own geometry) and by hipMemsetAsync; GBps = the best of them'}
+    except Exception as exc:                              # pragma: no cover - a probe failure must not lose the line
+        out['box_write_ceiling'] = {'error': repr(exc)}
+    s.close()
+    return out
+
+
+def attach_traffic(roof, workload, obs, custom_envs):
     """HBM bytes per launch come from rocprofv3 PMC passes, which cannot be collected from inside this process: the
-    figure is taken from the newest committed summary for this kernel and workload, but only if that summary was
+    figure is QUOTED from the newest committed summary for this kernel and workload, and only if that summary was
     made from the SAME kernel sources that are running now (digest of csrc/ recorded by tools/summarize_profiles.py);
     otherwise it stays null and the mismatch is reported."""
-    if args.envs:
+    if custom_envs:
         return
     from gym_d2d_amd.build import source_digest
     digest = source_digest()
@@ -580,14 +761,14 @@ def attach_traffic(roof, args, w):
             rec = json.loads(path.read_text())
         except Exception:
             continue
-        if rec.get('workload_key') != f'{args.workload}/{args.obs}':
+        if rec.get('workload_key') != f'{workload}/{obs}':
             continue
         for kname, d in rec.get('kernels', {}).items():
             if roof['kernel'].split(' ')[0] in kname and 'hbm_bytes_per_launch' in d:
                 if rec.get('source_digest') == digest:
                     roof['traffic'] = d['hbm_bytes_per_launch']
-                    roof['traffic_source'] = (f'profiles/{path.name} (WRITE_SIZE + 2*FETCH_SIZE, separate --pmc passes; '
-                                              f'kernel sources {digest[:12]} = the ones running)')
+                    roof['traffic_source'] = (f'QUOTED, not measured in this run: profiles/{path.name} (WRITE_SIZE + 2*FETCH_SIZE, '
+                                              f'separate --pmc passes; kernel sources {digest[:12]} = the ones running)')
                 else:
                     roof['traffic_stale'] = (f'profiles/{path.name} was collected for kernel sources '
                                              f'{str(rec.get("source_digest"))[:12]}, running {digest[:12]}')

@@ -26,7 +26,7 @@ OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
 FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
 (TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK, TUNE_OBS_VARIANT,
  TUNE_STEP_THREADS, TUNE_STEP_ENVS_PER_WG, TUNE_STEP_BLOCK, TUNE_STEP_FUSE_OBS, TUNE_STEP_ABLATE,
- TUNE_STEP_WALK, TUNE_STEP_PREFETCH, TUNE_STEP_LPT) = range(13)
+ TUNE_STEP_WALK, TUNE_STEP_PREFETCH, TUNE_STEP_LPT, TUNE_STEP_NT_RESULTS, TUNE_STEP_SCALAR_RECORDS) = range(15)
 UNIQUE_ID_BYTES = 128
 
 BUFFER_DTYPES = {BUF_ACTIONS: np.int32, BUF_RB: np.int32, BUF_PWR: np.int32, BUF_ENV_FLAGS: np.int32}
@@ -100,6 +100,7 @@ SIGNATURES = {
     'd2d_profile_read': (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'd2d_profile_reset': (C.c_int, [_P]),
     'd2d_probe_write_bandwidth': (C.c_int, [_P, C.c_size_t, _I, C.POINTER(C.c_double)]),
+    'd2d_probe_write_variants': (C.c_int, [_P, C.c_size_t, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -354,6 +355,13 @@ class Handle:
 
     def profile_reset(self) -> None:
         _check(self._lib.d2d_profile_reset(self._h))
+
+    def probe_write_variants(self, nbytes: int, iters: int = 5):
+        """(best GB/s, [per-variant GB/s ..., hipMemsetAsync]) - see d2d_probe_write_variants."""
+        n = 33
+        best, arr = C.c_double(), (C.c_double * n)()
+        _check(self._lib.d2d_probe_write_variants(self._h, nbytes, iters, C.byref(best), arr, n))
+        return best.value, list(arr)
 
     def probe_write_bandwidth(self, nbytes: int, iters: int = 10) -> float:
         g = C.c_double()

@@ -24,6 +24,7 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc',
          # the kernels already issue their uniform-address LDS atomics from one lane (or on rare paths): LLVM's atomic optimizer
          # only wraps them in mbcnt / readlane / popcount-multiply sequences
          '-mllvm', '-amdgpu-atomic-optimizer-strategy=None']
+FLAGS += os.environ.get('D2D_BUILD_DEFINES', '').split()       # experiment builds (tools/ab_builds.py), e.g. -DD2D_EXP_PF_POS=1
 if os.environ.get('D2D_BUILD_DIAG') == '1':          # diagnostic build: the step kernel honours D2D_TUNE_STEP_ABLATE
     FLAGS.append('-DD2D_STEP_ABLATE=1')
 

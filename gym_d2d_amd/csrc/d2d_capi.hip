@@ -75,6 +75,7 @@ struct d2d_handle {
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
     bool lpos_dirty = true;
     unsigned long long* dbg = nullptr;   // diagnostic builds only
+    bool rec_uniform = false;       // records identical within every aligned group of 64 links (refresh_tables)
     bool std_layout = false;        // link i < C is (cue i -> mbs), link C + k is (due 2k -> due 2k+1): d2d_reset_positions writes lpos itself
     float* gain_table = nullptr;
     size_t gain_elems = 0;
@@ -96,6 +97,7 @@ struct d2d_handle {
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
     int num_cus = 0;
     int tune_step_prefetch = -1;                     // action prefetch distance in envs: -1 auto, 0 off
+    int tune_step_nt = -1, tune_step_srec = -1;      // nontemporal result stores / scalar record loads: -1 auto, 0 off, 1 on (if legal)
     int tune_step_epw = 0, tune_step_block = 0, tune_step_fuse = -1, tune_step_ablate = 0, tune_step_walk = -1, tune_step_lpt = -1;
     // d2d_step_host: packed device block + pinned host mirrors
     void* host_out_dev = nullptr; size_t host_out_bytes = 0;
@@ -219,6 +221,20 @@ int refresh_tables(d2d_handle* h) {
         std_layout = i < C ? (h->host_tx[i] == i + 1 && h->host_rx[i] == 0)
                            : (h->host_tx[i] == C + 1 + 2 * (i - C) && h->host_rx[i] == C + 2 + 2 * (i - C));
     h->std_layout = std_layout;
+    // Are the records of every aligned group of 64 links identical, device ids and action column aside?  (Homogeneous
+    // device classes with the class boundary on a multiple of 64: BASELINE configs 3-5.)  The rollout kernel then reads
+    // them with one scalar load per wave instead of 64 x 48 bytes per wave.
+    bool uniform = N > 0 && N % 64 == 0;
+    for (int i = 0; i < N && uniform; ++i) {
+        const int g = i & ~63;
+        uniform = (ra[4 * i] >> D2D_REC_TYPE_SHIFT) == (ra[4 * g] >> D2D_REC_TYPE_SHIFT) && ra[4 * i + 2] == ra[4 * g + 2] &&
+                  ra[4 * i + 3] == ra[4 * g + 3] && std::memcmp(&rb[4 * i], &rb[4 * g], 16) == 0 &&
+                  std::memcmp(&rc[4 * i], &rc[4 * g], 12) == 0;
+        uint32_t pi, pg;
+        std::memcpy(&pi, &rc[4 * i + 3], 4); std::memcpy(&pg, &rc[4 * g + 3], 4);
+        uniform = uniform && (pi & 0xFFFFu) == (pg & 0xFFFFu);
+    }
+    h->rec_uniform = uniform;
     h->tables_dirty = false;
     h->lpos_dirty = true;                       // the link -> device map may have changed
     return D2D_OK;
@@ -330,6 +346,11 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         return fail(D2D_ERR_UNSUPPORTED, "envs x links per GPU must stay below 2^32 / 24 (32-bit byte offsets in the step kernel)");
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
+    // nontemporal result stores: measured -0.7 ... -1.5 us in per-process A/Bs and +0.6 ... 0 us interleaved in one process
+    // (profiles/r3_ab_*): no consistent gain, so off unless asked for.  Never with LinearObs: the expansion kernel reads the
+    // table right behind this launch.
+    s.nt_results = h->tune_step_nt > 0 && h->obs_mode != D2D_OBS_LINEAR;
+    s.rec_uniform = h->rec_uniform && h->tune_step_srec != 0;
     s.ablate = h->tune_step_ablate;
     s.dbg = nullptr;
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
@@ -338,7 +359,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         s.dbg = h->dbg;
     }
 #endif
-    s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : 0;
+    s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (N > 1024 ? 2 : 0);   // masks cover N <= 1024; beyond, the member lists
 
     // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
     // workgroup (N = 50: four 64-thread envs in 256 threads), and for small N the LinearObs expansion runs inside the
@@ -502,7 +523,10 @@ int load_rccl() {
     // a process that already has RCCL mapped (torch.distributed) must share that copy, not load a second one
     for (const char* n : names) if (n && !lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     for (const char* n : names) if (n && !lib) lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!lib) return fail(D2D_ERR_UNSUPPORTED, std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"));
+    if (!lib) {
+        const char* why = dlerror();              // one call: dlerror() clears the message it returns
+        return fail(D2D_ERR_UNSUPPORTED, std::string("librccl not found: ") + (why ? why : "?"));
+    }
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
@@ -535,6 +559,8 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
         return fail(D2D_ERR_INVALID, "num_envs/num_rbs must be >= 1 and device counts >= 0");
     if (cfg->pwr_levels_due < 1 || cfg->pwr_levels_cue < 1 || cfg->pwr_levels_mbs < 1)
         return fail(D2D_ERR_INVALID, "power level counts must be >= 1");
+    if (cfg->pwr_levels_due > 65535 || cfg->pwr_levels_cue > 65535 || cfg->pwr_levels_mbs > 65535)
+        return fail(D2D_ERR_INVALID, "power level counts must be <= 65535 (16 bits of the link record)");
     int nmax = cfg->max_links > 0 ? cfg->max_links : cfg->num_cues + cfg->num_due_pairs;
     if (nmax < 1 || nmax > D2D_MAX_LINKS)
         return fail(D2D_ERR_INVALID, "max_links must be in [1, " + std::to_string(D2D_MAX_LINKS) + "]");
@@ -813,6 +839,14 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
             if (value != 0) return fail(D2D_ERR_UNSUPPORTED, "D2D_TUNE_STEP_ABLATE needs the diagnostic build (D2D_BUILD_DIAG=1 python -m gym_d2d_amd.build)");
             break;
 #endif
+        case D2D_TUNE_STEP_NT_RESULTS:
+            if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "nt_results must be -1, 0 or 1");
+            h->tune_step_nt = value;
+            break;
+        case D2D_TUNE_STEP_SCALAR_RECORDS:
+            if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "scalar_records must be -1, 0 or 1");
+            h->tune_step_srec = value;
+            break;
         case D2D_TUNE_STEP_FUSE_OBS:
             if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "fuse_obs must be -1, 0 or 1");
             h->tune_step_fuse = value;
@@ -1087,23 +1121,40 @@ int d2d_profile_reset(d2d_handle* h) {
 }
 
 int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s) {
-    if (!h || !gb_per_s || iters < 1 || bytes < 16) return fail(D2D_ERR_INVALID, "bad argument");
+    return d2d_probe_write_variants(h, bytes, iters, gb_per_s, nullptr, 0);
+}
+
+int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s, double* per_variant, int32_t n) {
+    if (!h || !best_gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
+    if (n < 0 || (n > 0 && !per_variant)) return fail(D2D_ERR_INVALID, "bad argument");
+    const size_t group = (size_t)8 * 512 * 1024 * 16;         // whole groups of 8 regions of 512 rows (64 MiB at the widest row)
+    if (bytes < group) return fail(D2D_ERR_INVALID, "the probe needs at least 64 MiB");
     USE_DEVICE(h);
     float* tmp = nullptr;
     HIP_TRY(hipMalloc(&tmp, bytes));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(d2d::launch_fill(tmp, bytes / 16, 1.0f, h->stream));   // warm-up / page touch
-    HIP_TRY(hipEventRecord(e0, h->stream));
-    for (int k = 0; k < iters; ++k) HIP_TRY(d2d::launch_fill(tmp, bytes / 16, (float)k, h->stream));
-    HIP_TRY(hipEventRecord(e1, h->stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const int variants = d2d::fill_variants();
+    double best = 0.0;
+    for (int v = 0; v <= variants; ++v) {                      // v == variants: the runtime's own fill (hipMemsetAsync)
+        size_t written = bytes / 16;
+        for (int k = -1; k < iters; ++k) {                     // k == -1: warm-up / page touch
+            if (k == 0) HIP_TRY(hipEventRecord(e0, h->stream));
+            if (v < variants) HIP_TRY(d2d::launch_fill(tmp, bytes / 16, (float)k, h->stream, v, &written));
+            else HIP_TRY(hipMemsetAsync(tmp, k & 0xFF, written * 16, h->stream));
+        }
+        HIP_TRY(hipEventRecord(e1, h->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        const double rate = (double)(written * 16) * iters / (ms * 1e-3) / 1e9;
+        if (v < n) per_variant[v] = rate;
+        if (rate > best) best = rate;
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     HIP_TRY(hipFree(tmp));
-    *gb_per_s = (double)(bytes / 16 * 16) * iters / (ms * 1e-3) / 1e9;
+    *best_gb_per_s = best;
     return D2D_OK;
 }
 

@@ -52,6 +52,8 @@ struct StepArgs {
     int reward_fn;
     float reward_param;
     int write_table;
+    int rec_uniform;         // every aligned group of 64 links has identical records (device ids aside): scalar record loads
+    int nt_results;          // nontemporal result stores (nothing re-reads them from L2 right behind this launch)
     int ablate;              // DIAGNOSTIC builds only (-DD2D_STEP_ABLATE=1): skip parts of the kernel to time the rest
     unsigned long long* dbg; // DIAGNOSTIC builds only: [workgroup][wave][8] shader-clock stamps at the phase boundaries, or null
     // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)
@@ -105,7 +107,8 @@ struct ObsArgs {
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
-hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream);
+hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written);
+int fill_variants();
 size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists);
 void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out);
 hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);

@@ -151,24 +151,44 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Streaming-store probe (d2d_probe_write_bandwidth): the same store pattern as the obs kernel - every workgroup
-// writes one contiguous slab with 16-B nontemporal stores - but with no LDS reads and no index arithmetic.  It is
-// the on-box ceiling the obs kernel is compared with.
-__global__ __launch_bounds__(256) void fill_kernel(f32x4* dst, size_t n, unsigned slab, float value) {
+// Streaming-store probe (d2d_probe_write_bandwidth): pure fill kernels - no table, no LDS, no source selection - in a family
+// of store geometries that contains the obs kernel's own (one thread per float4 column of a 6N-float row: 768 threads at
+// N = 512, two rows per workgroup, XCD-grouped dispatch order, nontemporal 16-byte stores).  The best of the family (and
+// of the runtime's own hipMemsetAsync) is the box's write ceiling as far as this library can demonstrate one.
+template <bool NT>
+__global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, unsigned chunks, unsigned rows_per_wg, unsigned rows_per_env, int xcd, float value) {
+    unsigned env, chunk;
+    if (xcd) {
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
+        chunk = rest % chunks; env = (rest / chunks) * 8u + lane8;
+    } else {
+        env = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
+    }
+    const unsigned T = blockDim.x;                             // float4 per row
     const f32x4 v = {value, value, value, value};
-    const size_t base = (size_t)blockIdx.x * slab;
-    const unsigned count = (unsigned)(n - base < slab ? n - base : slab);
-    f32x4* p = dst + base;
-#pragma unroll 4
-    for (unsigned k = threadIdx.x; k < count; k += 256) __builtin_nontemporal_store(v, p + k);
+    f32x4* o4 = dst + ((size_t)env * rows_per_env + (size_t)chunk * rows_per_wg) * T + threadIdx.x;
+#pragma unroll 2
+    for (unsigned i = 0; i < rows_per_wg; ++i) {
+        if (NT) __builtin_nontemporal_store(v, o4 + (size_t)i * T); else o4[(size_t)i * T] = v;
+    }
 }
 
-hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream) {
-    const unsigned slab = 6144;     // 96 KiB per workgroup = 8 obs rows at N = 512
-    const size_t blocks = (n_float4 + slab - 1) / slab;
-    if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<f32x4*>(dst),
-                       n_float4, slab, value);
+// Variant v of the family: block in {768, 1024, 512, 256} x rows per workgroup in {2, 4, 8, 32} x {nt, plain}, XCD-grouped
+// order; v == 0 is the obs kernel's geometry.  "Envs" are regions of 512 rows; n_float4 is rounded DOWN to whole groups of
+// 8 regions; returns the float4 actually written through *written.
+int fill_variants() { return 4 * 4 * 2; }
+
+hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written) {
+    static const unsigned blocks[4] = {768, 1024, 512, 256}, rows[4] = {2, 4, 8, 32};
+    const unsigned T = blocks[variant & 3], rows_per_wg = rows[(variant >> 2) & 3], rows_per_env = 512, chunks = rows_per_env / rows_per_wg;
+    const bool nt = ((variant >> 4) & 1) == 0;
+    const size_t env_f4 = (size_t)rows_per_env * T;
+    const size_t envs = (n_float4 / env_f4) & ~(size_t)7;
+    if (written) *written = envs * env_f4;
+    if (envs == 0) return hipSuccess;
+    const dim3 grid((unsigned)(envs * chunks)), block(T);
+    if (nt) hipLaunchKernelGGL(fill_kernel<true>, grid, block, 0, stream, reinterpret_cast<f32x4*>(dst), chunks, rows_per_wg, rows_per_env, 1, value);
+    else hipLaunchKernelGGL(fill_kernel<false>, grid, block, 0, stream, reinterpret_cast<f32x4*>(dst), chunks, rows_per_wg, rows_per_env, 1, value);
     return hipGetLastError();
 }
 

@@ -232,8 +232,16 @@ struct LinkRaw {
     int act0, act1;      // raw action, or explicit (rb, pwr)
 };
 
+// load through the constant address space: with a wave-uniform address the compiler selects s_load_dwordx4 (the data is
+// written by the host between launches only)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 scalar_load16(const void* p) {
+    typedef const __attribute__((address_space(4))) i32x4* cptr;
+    return *reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(p));
+}
+
 __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, unsigned act_row, int i, int action_mode, int col_mode,
-                                             bool no_fixed = false) {
+                                             bool no_fixed = false, bool srec = false) {
     LinkRaw in;
     in.act0 = 0; in.act1 = 0;
     // actions first, branch-free per lane (uniform branches only), so that no join forces a wait on the loads in flight
@@ -254,9 +262,19 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
         in.act0 = *at(a.rb_in, oe);
         in.act1 = *at(a.pwr_in, oe);
     }
-    in.ra = a.rec_a[i];
-    in.rb_ = a.rec_b[i];
-    in.rc = a.rec_c[i];
+    if (srec) {
+        // the records of this wave's 64 links are identical (StepArgs::rec_uniform, checked by the host; device ids aside,
+        // which only the table route reads): ONE scalar load per row and wave into SGPRs instead of 64 lanes x 16 bytes
+        const int iu = __builtin_amdgcn_readfirstlane(i);
+        const i32x4 va = scalar_load16(a.rec_a + iu), vb = scalar_load16(a.rec_b + iu), vc = scalar_load16(a.rec_c + iu);
+        in.ra = make_int4(va.x, va.y, va.z, va.w);
+        in.rb_ = make_float4(__int_as_float(vb.x), __int_as_float(vb.y), __int_as_float(vb.z), __int_as_float(vb.w));
+        in.rc = make_float4(__int_as_float(vc.x), __int_as_float(vc.y), __int_as_float(vc.z), __int_as_float(vc.w));
+    } else {
+        in.ra = a.rec_a[i];
+        in.rb_ = a.rec_b[i];
+        in.rc = a.rec_c[i];
+    }
     in.pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
     return in;
 }
@@ -350,6 +368,8 @@ __device__ __forceinline__ void clear_masks(const Smem& s, int R, int W, int lt,
 #define KEPT(u) (LPT > 0 ? (u) : 0)                /* register slot of link u (strided kernels keep only their first) */
 #define IN_REGS(u) (LPT > 0 || (u) == 0)
 
+// result stores of the rollout kernel: nontemporal when nothing re-reads them from L2 right behind this launch (OPT_NT)
+#define ST(ptr, val) do { if (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 #ifndef D2D_STEP_ABLATE
 #define D2D_STEP_ABLATE 0       /* diagnostic build: honour StepArgs::ablate (tools/ab_step.py ablate) */
 #endif
@@ -378,9 +398,13 @@ __device__ __forceinline__ void clear_masks(const Smem& s, int R, int W, int lt,
 // to initialise per env instead of 17 KB of masks.  An env in which some RB drew a ninth link (6 % of envs under uniformly
 // random actions at 512 links on 256 RBs) raises a workgroup flag; its workgroup then clears and builds the masks behind two
 // extra barriers and walks them, so the cost stays proportional to the same-RB pairs for any action distribution.
-template <int MODE, int LPT, bool FULL, int HOT = 0, bool LISTS = false>
+#define OPT_LISTS 1      /* generic kernels: per-RB member lists instead of the masks (StepArgs::walk == 2) */
+#define OPT_SREC 2       /* rollout kernel: link records by scalar loads (StepArgs::rec_uniform) */
+#define OPT_NT 4         /* rollout kernel: nontemporal result stores (StepArgs::nt_results) */
+template <int MODE, int LPT, bool FULL, int HOT = 0, int OPT = 0>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr int KEEP = LPT > 0 ? LPT : 1;
+    constexpr bool LISTS = (OPT & OPT_LISTS) != 0, SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0;
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
     const int cfg_col_mode = HOT ? 0 : a.col_mode;
     const int cfg_reward_fn = HOT ? 1 : a.reward_fn;
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) {
         const int i = lt + u * TPE;
-        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1);
+        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1, SREC);
     }
     // ---- pass 0: clear masks and flags
     const bool have_masks = HOT || W > 0;                          // mask region allocated
@@ -461,7 +485,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                                                                          // route wants the type, and reads it from the record)
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
-        if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); *at(a.rb_out, oe) = rb; *at(a.pwr_out, oe) = p; }
+        if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); ST(at(a.rb_out, oe), rb); ST(at(a.pwr_out, oe), p); }
         if (LISTS) {
             if (LIKELY((unsigned)rb < (unsigned)R)) {
                 const unsigned slot = atomicAdd(&s.cnt[rb], 1u);                         // ds_add_rtn_u32
@@ -482,7 +506,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             // sidelink membership words are a property of the link list: built on the host (StepArgs::side_words).  Only
             // CueSinrShannon reads them in its hot loop and wants them in LDS; SystemCapacity's -1 rule reads the global copy
             if (cfg_reward_fn == 3 && (i & 31) == 0) s.side[i >> 5] = a.side_words[i >> 5];
-        }
+        } else if (!LISTS && UNLIKELY((unsigned)rb >= (unsigned)R)) atomicOr(&s.flags[0], FLAG_RB_OOR);   // all-pairs sweep: flagged all the same
     }
     STAMP(3);
     if (!ABL(64)) __syncthreads();
@@ -745,17 +769,23 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 
         if (!ABL(8)) {
             const unsigned o4 = fresh((row + (unsigned)i) * 4u);
-            *at(a.sinr_db, o4) = sinr_db;
-            *at(a.snr_db, o4) = snr_db;
-            *at(a.rate, o4) = rate;
-            *at(a.cap, o4) = cap;
+            ST(at(a.sinr_db, o4), sinr_db);
+            ST(at(a.snr_db, o4), snr_db);
+            ST(at(a.rate, o4), rate);
+            ST(at(a.cap, o4), cap);
         }
         if (cfg_write_table && !ABL(16)) {                                 // obs_fn.py:57-60
             const unsigned o4t = fresh((row + (unsigned)i) * 4u);
             float2* t = reinterpret_cast<float2*>(at(a.table, (o4t << 2) + (o4t << 1)));      // 24 bytes per link, no v_mul_lo
-            t[0] = make_float2(me.x, me.y);
-            t[1] = rx;
-            t[2] = make_float2(sinr_db, snr_db);
+            if (NT) {
+                f32x2* tv = reinterpret_cast<f32x2*>(t);
+                const f32x2 v0 = {me.x, me.y}, v1 = {rx.x, rx.y}, v2 = {sinr_db, snr_db};
+                __builtin_nontemporal_store(v0, tv); __builtin_nontemporal_store(v1, tv + 1); __builtin_nontemporal_store(v2, tv + 2);
+            } else {
+                t[0] = make_float2(me.x, me.y);
+                t[1] = rx;
+                t[2] = make_float2(sinr_db, snr_db);
+            }
         }
         if (!FULL && (HOT == 2 || a.fuse_obs)) {
             float2* t = reinterpret_cast<float2*>(s.tflat + 6 * i);
@@ -819,21 +849,29 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         int ticket = 0;
         if (cfg_reward_fn == 1) {
             const float wsum = wave_sum(cap_part);
-            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), to_fixed_32_32(wsum));
+            // a non-finite wave sum (zero distance: inf capacity) cannot go through the fixed-point accumulator: the env's
+            // reward is then what the generic path's float sum gives - inf, or NaN once a NaN is among the parts
+            if (UNLIKELY(!(wsum <= 4.0e9f))) atomicOr(&s.flags[1], wsum != wsum ? 4 : 2);
+            else if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), to_fixed_32_32(wsum));
             if (violated) atomicOr(&s.flags[1], 1);
         }
         // consume the prefetched word here, at the end: an empty asm that names the register keeps the load alive and costs
         // no instruction (the wait for it lands here, long after it has arrived)
         asm volatile("" ::"v"(pf));
+        // release: this wave's LDS atomics above are ordered before its ticket (the LDS queue is in order; the fence keeps the
+        // compiler from sinking them below it); acquire: the last wave's reads below stay behind its own ticket
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) ticket = atomicAdd(&s.flags[2], 1);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (ticket == (TPE >> 6) - 1) {
             if (cfg_reward_fn == 1) {
                 // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone on a violation
                 const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long*>(s.red), 0ull);   // LDS read that cannot be hoisted
                 const float total = (float)tot * 2.3283064365386963e-10f;
-                const float r = atomicOr(&s.flags[1], 0) ? -1.0f : total * a.inv_n;
-                for (int k = lane; k < N; k += 64) *at(a.reward, fresh((row + (unsigned)k) * 4u)) = r;
+                const int viol = atomicOr(&s.flags[1], 0);
+                const float r = (viol & 1) ? -1.0f : ((viol & 4) ? __int_as_float(0x7FC00000) : ((viol & 2) ? __int_as_float(0x7F800000) : total * a.inv_n));
+                for (int k = lane; k < N; k += 64) ST(at(a.reward, fresh((row + (unsigned)k) * 4u)), r);
             }
             if (lane == 0) a.env_flags[b] = atomicOr(&s.flags[0], 0);
         }
@@ -1001,12 +1039,13 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
     const bool lists = a.walk == 2 && lpt > 0 && a.reward_fn != 3;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
-                     (a.walk == 0 || a.walk == 2) && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
+                     a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
+    const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0);
     // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
-                      (a.walk == 0 || a.walk == 2) && a.prefetch_envs > 0 && a.ablate == 0 && a.mask_words > 0 &&
+                      a.walk == 0 && a.prefetch_envs > 0 && a.ablate == 0 && a.mask_words > 0 &&
                       a.fuse_obs == 4 && a.obs_q_per_row > 0 && (unsigned)block_threads / a.obs_q_per_row >= 1u &&
                       (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
@@ -1019,27 +1058,43 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
             err = hipGetLastError();                                                                     \
         }                                                                                                \
     } while (0)
+#define D2D_LAUNCH_HOT1(M)                                                                               \
+    do {                                                                                                 \
+        switch (hot_opt) {                                                                               \
+            case 0: D2D_LAUNCH_1(M, 1, true, 1, 0); break;                                               \
+            case OPT_SREC: D2D_LAUNCH_1(M, 1, true, 1, OPT_SREC); break;                                 \
+            case OPT_NT: D2D_LAUNCH_1(M, 1, true, 1, OPT_NT); break;                                     \
+            default: D2D_LAUNCH_1(M, 1, true, 1, OPT_SREC | OPT_NT); break;                              \
+        }                                                                                                \
+    } while (0)
 #define D2D_LAUNCH_L(M, L)                                                                               \
     do {                                                                                                 \
-        if (lpt == 1 && full && hot) D2D_LAUNCH_1(M, 1, true, 1, L);                                     \
-        else if (lpt == 1 && !full && hot2) D2D_LAUNCH_1(M, 1, false, 2, L);                             \
-        else if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true, 0, L);                                       \
+        if (lpt == 2 && full) D2D_LAUNCH_1(M, 2, true, 0, L);                                            \
         else if (lpt == 2) D2D_LAUNCH_1(M, 2, false, 0, L);                                              \
         else if (lpt == 1 && full) D2D_LAUNCH_1(M, 1, true, 0, L);                                       \
         else if (lpt == 1) D2D_LAUNCH_1(M, 1, false, 0, L);                                              \
-        else D2D_LAUNCH_1(M, 0, false, 0, false);                                                        \
+        else D2D_LAUNCH_1(M, 0, false, 0, 0);                                                            \
+    } while (0)
+#define D2D_LAUNCH_COLD(M)                                                                               \
+    do {                                                                                                 \
+        if (lists) D2D_LAUNCH_L(M, OPT_LISTS);                                                           \
+        else D2D_LAUNCH_L(M, 0);                                                                         \
     } while (0)
 #define D2D_LAUNCH(M)                                                                                    \
     do {                                                                                                 \
-        if (lists) D2D_LAUNCH_L(M, true); else D2D_LAUNCH_L(M, false);                                   \
+        if (lpt == 1 && full && hot) D2D_LAUNCH_HOT1(M);                                                 \
+        else if (lpt == 1 && !full && hot2) D2D_LAUNCH_1(M, 1, false, 2, 0);                             \
+        else D2D_LAUNCH_COLD(M);                                                                         \
     } while (0)
     switch (mode) {
         case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;
         case PL_POWER: D2D_LAUNCH(PL_POWER); break;
-        case PL_TABLE: D2D_LAUNCH(PL_TABLE); break;
-        case PL_SHADOW: D2D_LAUNCH(PL_SHADOW); break;
+        case PL_TABLE: D2D_LAUNCH_COLD(PL_TABLE); break;          // the rollout specialisations exist for the power laws only
+        case PL_SHADOW: D2D_LAUNCH_COLD(PL_SHADOW); break;
     }
 #undef D2D_LAUNCH
+#undef D2D_LAUNCH_COLD
+#undef D2D_LAUNCH_HOT1
 #undef D2D_LAUNCH_L
 #undef D2D_LAUNCH_1
     return err;

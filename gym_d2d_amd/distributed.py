@@ -37,17 +37,30 @@ class StepGatherer:
 
         g = StepGatherer(b_local, n_links, device)
         g.gather_positions(table)              # after every reset: the 4 position columns, synchronous
-        g.launch(reward, table)                # after every step: rewards + (sinr, snr), asynchronous
+        g.launch(reward, table)                # after every step: rewards (+ (sinr, snr)), asynchronous
         rewards, signal = g.wait()             # [B_global], [B_global, N, 2]
         table = g.table()                      # [B_global, N, 6] assembled on demand
 
+    mode 'table' (default): every launch gathers the rewards and the per-step columns of T (16.8 MB per GPU at 4096 x 512:
+    sized against the 3.7 ms LinearObs step).  mode 'rewards': rewards only - B_local floats, 16 KB per GPU - for the
+    compact-obs step (32 us at 4096 x 512), which a 16.8 MB ring all-gather (>= 0.3 ms over one ~100 GB/s xGMI link per
+    hop) would outlast ten times over; the learner then reads observations through `signal_every`.
+    signal_every = K > 1: the (sinr, snr) columns ride along on every K-th launch only (the first included); `wait()` keeps
+    returning the last gathered signal and `signal_step` says which launch it belongs to.
+    per_agent_reward: gather rewards as [B, N] (Shannon / CueSinrShannon) instead of the env's scalar (SystemCapacity
+    broadcasts one value to every agent, reward_fn.py:44: column 0 is all of it).
+    timing: record CUDA events around every gather on the side stream; `gather_ms()` = mean ms per launch.
+
     backend 'torch' (default): torch.distributed collectives ("nccl" = RCCL on ROCm, "gloo" on CPU).
     backend 'native': the library's own RCCL entry (d2d_comm_init / d2d_allgather, include/d2d_hip.h) on `handle`;
-    torch.distributed is then only used once, to ship rank 0's 128-byte unique id to the other ranks.
+    torch.distributed is then only used once, to ship rank 0's 128-byte unique id to the other ranks.  Every native
+    collective - the per-episode position gather included - is issued on the ONE side stream, so two collectives of the
+    communicator are never in flight on unordered streams.
     """
 
     def __init__(self, b_local: int, n_links: int, device: torch.device, group=None, *, backend: str = 'torch',
-                 handle=None) -> None:
+                 handle=None, mode: str = 'table', signal_every: int = 1, per_agent_reward: bool = False,
+                 timing: bool = False) -> None:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -63,8 +76,15 @@ class StepGatherer:
                              'pad the batch to a multiple of the world size')
         if backend not in ('torch', 'native'):
             raise ValueError("backend must be 'torch' or 'native'")
+        if mode not in ('table', 'rewards'):
+            raise ValueError("mode must be 'table' or 'rewards'")
+        if signal_every < 1:
+            raise ValueError('signal_every must be >= 1')
         self.backend = backend
         self.handle = handle
+        self.mode = mode
+        self.signal_every = int(signal_every)
+        self.per_agent_reward = bool(per_agent_reward)
         if backend == 'native':
             if handle is None or not self.cuda:
                 raise ValueError("backend='native' needs the env's native handle and a CUDA device")
@@ -72,11 +92,20 @@ class StepGatherer:
             dist.broadcast_object_list(box, src=0, group=group)
             handle.comm_init(self.world, self.rank, box[0])
         f32 = torch.float32
-        self.stage_reward = torch.empty(b_local, dtype=f32, device=device)
-        self.stage_signal = torch.empty((b_local, n_links, 2), dtype=f32, device=device)
-        self.all_reward = torch.empty(self.world * b_local, dtype=f32, device=device)
-        self.all_signal = torch.empty((self.world * b_local, n_links, 2), dtype=f32, device=device)
+        rshape = (b_local, n_links) if per_agent_reward else (b_local,)
+        self.stage_reward = torch.empty(rshape, dtype=f32, device=device)
+        self.all_reward = torch.empty((self.world * b_local,) + rshape[1:], dtype=f32, device=device)
+        self.stage_signal = self.all_signal = None
+        if mode == 'table':
+            self.stage_signal = torch.empty((b_local, n_links, 2), dtype=f32, device=device)
+            self.all_signal = torch.zeros((self.world * b_local, n_links, 2), dtype=f32, device=device)
         self.all_positions = torch.zeros((self.world * b_local, n_links, 4), dtype=f32, device=device)
+        self.launches = 0
+        self.signal_step = -1                   # index of the launch the gathered signal belongs to
+        self.bytes_per_launch = self.stage_reward.numel() * 4
+        self.bytes_per_signal_launch = self.bytes_per_launch + (self.stage_signal.numel() * 4 if mode == 'table' else 0)
+        self._timing = bool(timing) and self.cuda
+        self._events = []
         if self.cuda:
             self.comm_stream = torch.cuda.Stream(device=device)
             self.staged = torch.cuda.Event()
@@ -90,38 +119,60 @@ class StepGatherer:
             dist.all_gather_into_tensor(out, local, group=self.group)
 
     def gather_positions(self, table: torch.Tensor) -> torch.Tensor:
-        """Once per episode: all ranks' (tx_x, tx_y, rx_x, rx_y) columns of T -> [B_global, N, 4]."""
-        local = table[:, :, :4].contiguous()
-        if self.backend == 'native':
-            self._all_gather(self.all_positions, local, torch.cuda.current_stream(self.device).cuda_stream)
+        """Once per episode: all ranks' (tx_x, tx_y, rx_x, rx_y) columns of T -> [B_global, N, 4].  Ordered after the
+        work already enqueued on the current stream and before whatever the caller enqueues next."""
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            self.comm_stream.wait_stream(cur)                   # the reset's rows are ready; earlier gathers precede us there
+            with torch.cuda.stream(self.comm_stream):
+                local = table[:, :, :4].contiguous()
+                local.record_stream(self.comm_stream)
+                self._all_gather(self.all_positions, local, self.comm_stream.cuda_stream)
+            cur.wait_stream(self.comm_stream)
         else:
-            self._all_gather(self.all_positions, local)
+            self._all_gather(self.all_positions, table[:, :, :4].contiguous())
         return self.all_positions
 
-    def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor) -> None:
+    def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor = None) -> None:
         """Call right after the step was enqueued on the current stream.  reward_per_agent [B_local, N] (column 0
-        is the env's scalar for SystemCapacity), table [B_local, N, 6]."""
+        is the env's scalar for SystemCapacity), table [B_local, N, 6] (mode 'table')."""
+        with_signal = self.mode == 'table' and self.launches % self.signal_every == 0
+        if with_signal and table is None:
+            raise ValueError("mode 'table' gathers the (sinr, snr) columns: pass the obs table")
+        src_reward = reward_per_agent if self.per_agent_reward else reward_per_agent[:, 0]
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)
             self.comm_stream.wait_stream(cur)                   # results of this step are ready
             with torch.cuda.stream(self.comm_stream):
-                self.stage_reward.copy_(reward_per_agent[:, 0])
-                self.stage_signal.copy_(table[:, :, 4:6])
+                if self._timing:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(self.comm_stream)
+                self.stage_reward.copy_(src_reward)
+                if with_signal:
+                    self.stage_signal.copy_(table[:, :, 4:6])
                 self.staged.record(self.comm_stream)
                 self._all_gather(self.all_reward, self.stage_reward, self.comm_stream.cuda_stream)
-                self._all_gather(self.all_signal, self.stage_signal, self.comm_stream.cuda_stream)
+                if with_signal:
+                    self._all_gather(self.all_signal, self.stage_signal, self.comm_stream.cuda_stream)
                 self.done.record(self.comm_stream)
+                if self._timing:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
+                    self._events.append((e0, e1))
             cur.wait_event(self.staged)                         # next step may overwrite table/reward now
         else:
-            self.stage_reward.copy_(reward_per_agent[:, 0])
-            self.stage_signal.copy_(table[:, :, 4:6])
+            self.stage_reward.copy_(src_reward)
             self._all_gather(self.all_reward, self.stage_reward)
-            self._all_gather(self.all_signal, self.stage_signal)
+            if with_signal:
+                self.stage_signal.copy_(table[:, :, 4:6])
+                self._all_gather(self.all_signal, self.stage_signal)
+        if with_signal:
+            self.signal_step = self.launches
+        self.launches += 1
         self._pending = True
 
     def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(rewards [B_global], signal [B_global, N, 2] = sinr_dB, snr_dB) of the last launched gather, rank-major =
-        global env order."""
+        """(rewards [B_global] (or [B_global, N]), signal [B_global, N, 2] = sinr_dB, snr_dB - None in mode 'rewards') of
+        the last launched gather, rank-major = global env order.  With signal_every > 1 the signal is that of launch
+        `signal_step`."""
         if self.cuda and self._pending:
             torch.cuda.current_stream(self.device).wait_event(self.done)
         self._pending = False
@@ -130,7 +181,23 @@ class StepGatherer:
     def table(self) -> torch.Tensor:
         """The global compact obs table [B_global, N, 6] = cached positions ++ latest gathered (sinr, snr)."""
         _, signal = self.wait()
+        if signal is None:
+            raise ValueError("mode 'rewards' gathers no observation columns")
         return torch.cat([self.all_positions, signal], dim=2)
+
+    def gather_ms(self) -> float:
+        """Mean milliseconds per launch between the gather's first staging copy and its last collective, measured with
+        events on the side stream (timing=True); synchronises.  0.0 when nothing was timed."""
+        if not self._events:
+            return 0.0
+        self._events[-1][1].synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in self._events) / len(self._events)
+        return ms
+
+    def reset_timing(self) -> None:
+        if self._events:
+            self._events[-1][1].synchronize()
+        self._events = []
 
 
 def expand_table(table: torch.Tensor, handle=None, out: torch.Tensor = None) -> torch.Tensor:

@@ -1,7 +1,7 @@
 """EnvConfig: the reference's configuration surface (gym_d2d/envs/env_config.py:10-37; documented in its
 README.md:106-125) with the same field names and defaults, so an env_config dict written for the reference is accepted
-unchanged and an unknown key raises TypeError exactly like the dataclass there.  Three extra keys (num_envs,
-device_ordinal, seed) describe the batch and the GPU.  `num_pwr_actions` centralises the action-space arithmetic that
+unchanged and an unknown key raises TypeError exactly like the dataclass there.  Four extra keys (num_envs,
+device_ordinal, seed, obs_dtype) describe the batch, the GPU and the observation dtype.  `num_pwr_actions` centralises the action-space arithmetic that
 the reference keeps in D2DEnv.__init__."""
 from __future__ import annotations
 
@@ -42,8 +42,11 @@ class EnvConfig:
     num_envs: int = 1                                   # B: independent environments stepped together on one GPU
     device_ordinal: int = 0                             # which GPU
     seed: Optional[int] = None                          # seed of the device-side RNG streams (reset, shadowing)
+    obs_dtype: str = 'float32'                          # 'float64' = the reference's observation dtype (obs_fn.py:51)
 
     def __post_init__(self) -> None:
+        if self.obs_dtype not in ('float32', 'float64'):
+            raise ValueError("obs_dtype must be 'float32' or 'float64'")
         self.devices: Dict[str, dict] = self.load_device_config()
 
     def load_device_config(self) -> dict:

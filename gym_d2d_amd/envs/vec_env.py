@@ -38,7 +38,8 @@ _OUTPUTS = (('sinr_db', _native.BUF_SINR_DB), ('snr_db', _native.BUF_SNR_DB), ('
 
 class VecD2DEnv:
     def __init__(self, env_config: Optional[dict] = None, num_envs: Optional[int] = None, *,
-                 cue_actions: str = 'agent', use_torch: Optional[bool] = None, first_env: int = 0) -> None:
+                 cue_actions: str = 'agent', use_torch: Optional[bool] = None, first_env: int = 0,
+                 export_actions: bool = True) -> None:
         """cue_actions: 'agent' - step() takes actions for CUEs and DUEs [B, C+P] (reference behaviour);
         'traffic' - CUE links follow the env's traffic model (round-robin RB at max power,
         traffic_model.py:15-22): their (rb, pwr) are constants of the kernel's link records
@@ -47,10 +48,18 @@ class VecD2DEnv:
         first_env: global index of env 0 when one logical batch is sharded over several GPUs (positions AND the
         random actions of reset() are keyed by global env index, so a sharded run reproduces the single-GPU run).
 
+        export_actions: False - the kernel does not write the decoded (rb, tx power) planes behind info['rb'] /
+        info['tx_pwr_dbm'] (d2d_set_export_actions: 8 of the step's 72 bytes per link; a rollout knows its own actions);
+        the two info entries are then None.
+
+        env_config['obs_dtype'] = 'float64' returns observations in the reference's dtype (obs_fn.py:51 builds float64
+        arrays); the default float32 is the kernels' own block, zero copy.
+
         reset() checks the status flags once and raises ValueError('math domain error') if two interacting devices
         coincide (what the reference's log10(0) does, path_loss.py:66); step() does not synchronise - poll
         status_flags() for FLAG_ZERO_DISTANCE / FLAG_NON_FINITE if positions are written from outside."""
         env_config = dict(env_config or {})
+        self.export_actions = bool(export_actions)
         obs_cls = env_config.pop('obs_fn', LinearObsFunction)
         rew_cls = env_config.pop('reward_fn', SystemCapacityRewardFunction)
         if num_envs is not None:
@@ -94,8 +103,12 @@ class VecD2DEnv:
             rb, pwr = sim.traffic_model.assignments(sim.devices)
             h.set_fixed_actions(np.arange(self.num_cues), rb, pwr)
         h.set_env_offset(first_env)
+        h.set_export_actions(self.export_actions)
+        self._obs64 = cfg.obs_dtype == 'float64'
         h.set_obs_mode(self.obs_fn.native_mode)
         h.set_reward(rid, float(getattr(self.reward_fn, 'native_param', 0.0)))
+        self._native_reward = bool(rid)
+        self._array_obs = isinstance(self.obs_fn, ArrayObsFunction)
         self.use_torch = (torch is not None and torch.cuda.is_available()) if use_torch is None else use_torch
         self._t = {}
         if self.use_torch:
@@ -130,12 +143,21 @@ class VecD2DEnv:
         if self.obs_fn.native_mode == _native.OBS_LINEAR:
             self._t['obs'] = alloc(_native.BUF_OBS, (b, n, 6 * n), torch.float32)
         self._stream_ptr = None
+        # the raw current-stream query (one C call, no Stream object) when this torch has it
+        raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._current_stream_ptr = (lambda: raw(index)) if raw is not None else \
+            (lambda: torch.cuda.current_stream(self.device).cuda_stream)
         self._follow_torch_stream()
+        # per-step constants of the torch path: the buffers never move, so the view, the info dict and the two possible
+        # `dones` vectors are built once
+        self._view_cache = None
+        self._dones = (torch.zeros(b, dtype=torch.bool, device=dev), torch.ones(b, dtype=torch.bool, device=dev))
 
     def _follow_torch_stream(self) -> None:
         """Run the library's kernels on torch's CURRENT stream (the null stream by default) so they are ordered with
         the torch ops that produce actions / consume results.  Re-bound only when the caller switches streams."""
-        ptr = torch.cuda.current_stream(self.device).cuda_stream
+        ptr = self._current_stream_ptr()
         if ptr != self._stream_ptr:
             self.simulator.handle.set_stream(ptr)
             self._stream_ptr = ptr
@@ -143,6 +165,8 @@ class VecD2DEnv:
     def _view(self) -> SimpleNamespace:
         sim = self.simulator
         if self.use_torch:
+            if self._view_cache is not None:
+                return self._view_cache
             v = dict(self._t)
         else:
             v = {name: sim.fetch(which) for name, which in _OUTPUTS if name != 'reward' or
@@ -153,7 +177,14 @@ class VecD2DEnv:
             if self.obs_fn.native_mode == _native.OBS_LINEAR:
                 v['obs'] = sim.fetch(_native.BUF_OBS)
         v.update(link_tx=sim.link_tx, link_rx=sim.link_rx, link_type=sim.link_type)
-        return SimpleNamespace(**v)
+        if not self.export_actions:
+            v['rb'] = v['pwr'] = None
+        view = SimpleNamespace(**v)
+        if self.use_torch:
+            self._view_cache = view
+            self._info = {'rb': view.rb, 'tx_pwr_dbm': view.pwr, 'snr_db': view.snr_db, 'sinr_db': view.sinr_db,
+                          'rate_bps': view.rate_bps, 'capacity_mbps': view.capacity_mbps}
+        return view
 
     # ------------------------------------------------------------------ gym-like API
     def _initial_action_highs(self):
@@ -209,18 +240,19 @@ class VecD2DEnv:
         self.num_steps += 1
         view = self._view()
         obs = self._observe(view)
-        rewards = view.reward if getattr(self.reward_fn, 'native_id', 0) else self.reward_fn.compute(view)
+        rewards = view.reward if self._native_reward else self.reward_fn.compute(view)
         done = self.num_steps >= EPISODE_LENGTH
-        dones = (torch.full((self.num_envs,), done, dtype=torch.bool, device=self.device) if self.use_torch
-                 else np.full(self.num_envs, done))
+        if self.use_torch:
+            return obs, rewards, self._dones[done], dict(self._info)
         info = {'rb': view.rb, 'tx_pwr_dbm': view.pwr, 'snr_db': view.snr_db, 'sinr_db': view.sinr_db,
                 'rate_bps': view.rate_bps, 'capacity_mbps': view.capacity_mbps}
-        return obs, rewards, dones, info
+        return obs, rewards, np.full(self.num_envs, done), info
 
     def _observe(self, view):
-        if isinstance(self.obs_fn, ArrayObsFunction):
-            return self.obs_fn.compute(view)
-        return view.obs
+        obs = self.obs_fn.compute(view) if self._array_obs else view.obs
+        if self._obs64:                                   # the reference's dtype (obs_fn.py:51), on request
+            obs = obs.double() if self.use_torch else np.asarray(obs, dtype=np.float64)
+        return obs
 
     def action_buffer(self):
         """The bound int32 [B, num_agents] action tensor (step() with no copy also accepts any contiguous int32 CUDA

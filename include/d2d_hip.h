@@ -188,6 +188,11 @@ typedef enum d2d_tuning {
                                       1 masks, flattened walk, 2 per-RB member lists (sorted in registers by the
                                       receiver; an env that puts more than 8 links on one RB falls back to the
                                       masks inside the launch); -1 = auto                                     */
+    D2D_TUNE_STEP_NT_RESULTS = 13, /* rollout kernel: nontemporal result stores: 1 on (ignored with LinearObs, whose
+                                      expansion kernel re-reads the table behind the step), 0 / -1 off (default:
+                                      no consistent gain measured)                                             */
+    D2D_TUNE_STEP_SCALAR_RECORDS = 14, /* rollout kernel: link records by one scalar load per wave when every aligned
+                                      group of 64 links has identical records; -1 = auto (on when legal), 0 off  */
     D2D_TUNE_STEP_ABLATE = 9,      /* DIAGNOSTIC builds only (D2D_BUILD_DIAG=1), the one key that DOES change
                                       results: bit mask of kernel parts to skip (1 interferer walk, 2 mask
                                       build, 4 mask clear, 8 result stores, 16 table store, 32 rb/pwr stores,
@@ -279,8 +284,16 @@ int d2d_profile_enable(d2d_handle* h, int32_t enabled);
  * accumulated device time in ms and launch count since the last reset.                             */
 int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
 int d2d_profile_reset(d2d_handle* h);
-/* Streaming-store probe: fills `bytes` of D2D_BUF_OBS `iters` times with 16-B stores and reports the
- * sustained rate - the on-box write ceiling the obs kernel is compared with.                       */
+/* Streaming-store probe: writes a scratch buffer of `bytes` (>= 64 MiB; rounded down to whole groups of
+ * eight 512-row regions) `iters` times with pure fill kernels - nothing to compute - in a family of store
+ * geometries that contains the obs kernel's own (768-thread workgroups, two 12-KiB rows each, XCD-grouped
+ * dispatch order, nontemporal 16-byte stores) and with hipMemsetAsync, and reports the BEST sustained rate:
+ * the box's write ceiling as far as this library can demonstrate one.  d2d_probe_write_variants also
+ * returns the first n per-variant rates (variant v: block {768,1024,512,256}[v & 3], rows per workgroup
+ * {2,4,8,32}[(v >> 2) & 3], nontemporal unless v & 16; index D2D_PROBE_VARIANTS = hipMemsetAsync).     */
+#define D2D_PROBE_VARIANTS 32
+int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s,
+                             double* per_variant, int32_t n);
 int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s);
 
 #ifdef __cplusplus

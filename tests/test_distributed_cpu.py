@@ -77,14 +77,65 @@ def test_shard_range_partitions_the_batch():
         shard_range(8, 2, 2)
 
 
-def test_two_rank_gather_matches_single_process(tmp_path):
-    world, global_envs = 2, 12
+@pytest.mark.parametrize('world,global_envs', [(2, 12), (8, 16)])
+def test_multi_rank_gather_matches_single_process(tmp_path, world, global_envs):
+    """World sizes 2 and 8 (BASELINE config 5's rank count) over gloo."""
     mp.spawn(_worker, args=(world, _free_port(), global_envs, str(tmp_path)), nprocs=world, join=True)
     reward, table, obs = _oracle_results(global_envs, 0, global_envs)
     assert np.array_equal(np.load(tmp_path / 'reward.npy'), reward[:, 0])
     assert np.array_equal(np.load(tmp_path / 'table.npy'), table)
     # the learner-side expansion of the gathered compact table == the expanded obs every rank holds locally
     assert np.array_equal(np.load(tmp_path / 'obs.npy'), obs)
+
+
+def _modes_worker(rank, world, port, out_dir):
+    """mode='rewards' (no observation columns travel) and signal_every=K (they travel on every K-th launch), and
+    per-agent rewards: every rank checks what it received against what every rank is known to have sent."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gym_d2d_amd.distributed import StepGatherer
+    b, n = 3, 5
+    dev = torch.device('cpu')
+
+    def local(r, step):                                 # what rank r's step `step` produced
+        reward = torch.arange(b * n, dtype=torch.float32).reshape(b, n) + 100.0 * r + 1000.0 * step
+        table = torch.full((b, n, 6), float(r)) + 0.5 * step
+        return reward, table
+    errors = []
+    g = StepGatherer(b, n, dev, mode='rewards')
+    for step in range(3):
+        g.launch(*local(rank, step))
+        rew, sig = g.wait()
+        want = torch.cat([local(r, step)[0][:, 0] for r in range(world)])
+        if sig is not None or not torch.equal(rew, want):
+            errors.append(f'rewards mode step {step}')
+    if g.bytes_per_launch != b * 4 or g.bytes_per_signal_launch != b * 4:
+        errors.append('rewards mode byte count')
+    try:
+        g.table()
+        errors.append('rewards mode table() did not raise')
+    except ValueError:
+        pass
+    g = StepGatherer(b, n, dev, signal_every=3, per_agent_reward=True)
+    for step in range(7):
+        g.launch(*local(rank, step))
+        rew, sig = g.wait()
+        want = torch.cat([local(r, step)[0] for r in range(world)])
+        last = (step // 3) * 3                          # launches 0, 3, 6 carry the signal
+        want_sig = torch.cat([local(r, last)[1][:, :, 4:6] for r in range(world)])
+        if not torch.equal(rew, want) or not torch.equal(sig, want_sig) or g.signal_step != last:
+            errors.append(f'signal_every step {step}')
+    (Path(out_dir) / f'rank{rank}.txt').write_text('; '.join(errors) or 'ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_rewards_only_and_every_kth_step_gather_modes(tmp_path, world):
+    mp.spawn(_modes_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert (tmp_path / f'rank{rank}.txt').read_text() == 'ok', rank
 
 
 def _uneven_worker(rank, world, port, out_dir):
@@ -136,6 +187,19 @@ def test_bench_self_launches_its_ranks():
     steps_done = 4
     assert line['allreduce_reward_checksum'] == 4 * (0 + steps_done) + 4 * (4 + steps_done)
     assert line['value'] > 0 and line['config']['envs_per_gpu'] == 4 and 'stub' in line
+
+
+def test_bench_self_launches_eight_ranks():
+    """BASELINE config 5's world size through the launcher and the gather plumbing (stub handle, gloo), with the
+    rewards-only gather plan."""
+    r, out = _run_bench(['--gpus', '8', '--stub-cpu', '--steps', '3', '--warmup', '1', '--envs', '2', '--workload', 'default',
+                         '--gather', 'rewards'], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = out[0]
+    assert line['n_gpus'] == 8 and line['rccl_ranks'] == 8 and line['allreduce_rank_count'] == 8.0
+    assert line['allgather_envs'] == 16 and line['checksums_agree'] is True and len(line['per_rank']) == 8
+    assert line['gather']['mode'] == 'rewards' and line['gather']['bytes_per_gpu_per_step'] == 2 * 4
+    assert abs(line['value_per_gpu'] * 8 - line['value']) < 1e-6 * line['value']
 
 
 def test_bench_launcher_propagates_a_failing_rank():

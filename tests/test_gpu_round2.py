@@ -260,8 +260,11 @@ def test_step_gatherer_native_backend_single_rank(native):
     import torch.distributed as dist
     from gym_d2d_amd.distributed import StepGatherer
     from gym_d2d_amd.envs import VecD2DEnv
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
-    dist.init_process_group('gloo', rank=0, world_size=1)
+    import socket
+    with socket.socket() as sock:                      # a free port: another job on the box may hold any fixed one
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
     try:
         env = VecD2DEnv({'num_rbs': 4, 'num_cues': 3, 'num_due_pairs': 4}, num_envs=16)
         env.reset(seed=1)
@@ -300,22 +303,28 @@ def test_step_host_returns_everything_in_one_block(native):
         sim.handle.close()
 
 
-def test_single_env_step_latency_budget(native):
-    """the drop-in D2DEnv.step is one packed copy each way - a loose wall-clock ceiling so that a
-    regression back to per-buffer synchronous copies is caught (measured figures live in DESIGN.md / bench JSON)."""
-    import time
+def test_single_env_step_is_one_packed_round_trip(native):
+    """the drop-in D2DEnv.step is ONE d2d_step_host call - one packed copy each way, one
+    synchronisation - and no per-buffer download.  (Structural, not a wall-clock bound: the measured latency is
+    `single_env_step_ms` in every N = 1 bench line.)"""
     from gym_d2d_amd.envs import D2DEnv
     env = D2DEnv({})
     obs = env.reset()
     acts = {k: env.action_space['due' if k.startswith('due') else 'cue'].sample() for k in obs}
+    h = env.simulator.handle
+    calls = {'step_host': 0, 'download': 0, 'upload': 0, 'step': 0, 'step_rb_pwr': 0, 'status_flags': 0}
+    for name in calls:
+        def wrap(fn, name=name):
+            def inner(*a, **k):
+                calls[name] += 1
+                return fn(*a, **k)
+            return inner
+        setattr(h, name, wrap(getattr(h, name)))
     for _ in range(20):
-        env.step(acts)
-    t0 = time.perf_counter()
-    for _ in range(200):
-        env.step(acts)
-    ms = (time.perf_counter() - t0) / 200 * 1e3
+        out = env.step(acts)
+    assert calls == {'step_host': 20, 'download': 0, 'upload': 0, 'step': 0, 'step_rb_pwr': 0, 'status_flags': 0}, calls
+    assert len(out[0]) == 50 and next(iter(out[0].values())).dtype == np.float64      # the reference's obs dtype
     env.close()
-    assert ms < 0.6, ms
 
 
 def test_device_reset_never_places_two_interacting_devices_together(native):

@@ -22,9 +22,9 @@ def native():
     return _native
 
 
-def _batch(num_envs, rbs, cues, dues, seed, **cfg):
+def _batch(num_envs, rbs, cues, dues, rng_seed, **cfg):
     from gym_d2d_amd.simulator import Simulator
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(rng_seed)
     sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=num_envs, **cfg))
     pos = random_layout(rng, num_envs, cues, dues)
     sim.set_positions(pos)
@@ -70,7 +70,7 @@ SHAPES = [(33, 25, 25, 25), (64, 256, 256, 256), (16, 4, 40, 60), (8, 7, 0, 130)
 @pytest.mark.parametrize('reward', [0, 1, 2, 3])
 def test_member_lists_are_bit_identical_to_masks_and_all_pairs(native, shape, reward):
     b, rbs, cues, dues = shape
-    sim, pos, raw = _batch(b, rbs, cues, dues, seed=sum(shape) + reward)
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=sum(shape) + reward)
     h = sim.handle
     h.set_obs_mode(native.OBS_TABLE)
     h.set_reward(reward, {0: 0.0, 1: 0.0, 2: -70.0, 3: 0.0}[reward])
@@ -97,7 +97,7 @@ def test_member_lists_with_skewed_actions_and_out_of_range_rbs(native):
     """Action distributions a policy can produce: every DUE on one of 3 RBs (lists overflow in every env), exactly two links
     per RB (no overflow anywhere), and envs with rb outside [0, R) (those links take the sweep, the others their lists)."""
     b, rbs, cues, dues = 40, 64, 64, 64
-    sim, pos, raw = _batch(b, rbs, cues, dues, seed=77)
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=77)
     h = sim.handle
     h.set_obs_mode(native.OBS_TABLE)
     h.set_reward(1, 0.0)
@@ -133,7 +133,7 @@ def test_member_lists_every_path_loss_mode(native, model):
 
     cls = {'ple35': Ple35, 'cost_hata': pl.CostHataPathLoss, 'table': Plugin, 'shadowing': pl.ShadowingPathLoss}[model]
     b, rbs, cues, dues = (12, 6, 20, 30) if model != 'table' else (1, 6, 20, 30)
-    sim, pos, raw = _batch(b, rbs, cues, dues, seed=5, path_loss_model=cls, **({'seed': 99} if model == 'shadowing' else {}))
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=5, path_loss_model=cls, **({'seed': 99} if model == 'shadowing' else {}))
     h = sim.handle
     h.set_obs_mode(native.OBS_TABLE)
     for reward in (1, 2):
@@ -153,7 +153,7 @@ def test_member_lists_small_envs_sharing_a_workgroup_and_fused_obs(native, shape
     """Several envs per workgroup: an overflow in ONE env sends the whole workgroup through the mask fallback; the fused
     LinearObs expansion rides on either path.  Traffic-model CUEs as in BASELINE config 2."""
     b, rbs, cues, dues = shape
-    sim, pos, raw = _batch(b, rbs, cues, dues, seed=sum(shape))
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=sum(shape))
     h = sim.handle
     h.set_obs_mode(native.OBS_LINEAR)
     ref = None
@@ -226,7 +226,7 @@ def test_full_size_member_lists_against_masks(native):
 
 def test_export_actions_switch(native):
     """d2d_set_export_actions(0): D2D_BUF_RB / PWR keep their last contents, every other output is unchanged."""
-    sim, pos, raw = _batch(16, 32, 48, 48, seed=9)
+    sim, pos, raw = _batch(16, 32, 48, 48, rng_seed=9)
     h = sim.handle
     h.set_obs_mode(native.OBS_TABLE)
     sim.step_arrays(raw)
@@ -248,3 +248,88 @@ def test_export_actions_switch(native):
         for buf in OUTS:
             assert np.array_equal(snap[buf], ref[buf]), buf
     sim.handle.close()
+
+
+def test_rollout_kernel_options_are_bit_identical(native):
+    """The rollout specialisation's options - link records by scalar loads (legal when every aligned group of 64 links has
+    identical records), nontemporal result stores - change no bit of any output; with a per-device override the records
+    stop being uniform, the library drops the scalar loads by itself, and the results still equal the generic kernel's."""
+    import json
+    import tempfile
+    from pathlib import Path
+    from gym_d2d_amd.simulator import Simulator
+    b, rbs, cues, dues = 48, 128, 128, 128            # N = 256 = one link per thread, one env per workgroup
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=21)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+    ref = None
+    for srec in (0, 1):
+        for nt in (0, 1):
+            h.set_tuning(native.TUNE_STEP_SCALAR_RECORDS, srec)
+            h.set_tuning(native.TUNE_STEP_NT_RESULTS, nt)
+            sim.step_arrays(raw)
+            snap = _snapshot(sim, native)
+            ref = ref or snap
+            for buf, r in ref.items():
+                assert np.array_equal(snap[buf], r), (srec, nt, buf)
+    h.set_bucketing(False)                             # generic kernel, all-pairs sweep
+    sim.step_arrays(raw)
+    for buf, r in _snapshot(sim, native).items():
+        assert np.array_equal(ref[buf], r), buf
+    tx, rx, ty = default_links(cues, dues)
+    want = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(*orc.device_configs(cues, dues)[1:]),
+                         orc.PathLossSpec(), with_obs=False, chunk=8)
+    assert rel_err(ref['BUF_SINR_DB'], want['sinr_db']) <= TOL and rel_err(ref['BUF_REWARD'][:, 0], want['reward']) <= TOL
+    sim.handle.close()
+    # one CUE with its own antenna gain: records no longer uniform within its group of 64
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / 'devices.json'
+        path.write_text(json.dumps({'cue07': {'config': {'tx_antenna_gain_dBi': 3.5}}}))
+        rng = np.random.default_rng(21)
+        sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b, device_config_file=path))
+        sim.set_positions(pos)
+        sim.set_links(sim.default_link_keys())
+        h = sim.handle
+        h.set_obs_mode(native.OBS_TABLE)
+        outs = []
+        for srec, bucket in ((1, True), (0, True), (0, False)):
+            h.set_tuning(native.TUNE_STEP_SCALAR_RECORDS, srec)
+            h.set_bucketing(bucket)
+            sim.step_arrays(raw)
+            outs.append(_snapshot(sim, native))
+        for other in outs[1:]:
+            for buf, r in outs[0].items():
+                assert np.array_equal(other[buf], r), buf
+        assert not np.array_equal(outs[0]['BUF_SINR_DB'], ref['BUF_SINR_DB'])       # the override reached the kernel
+        sim.handle.close()
+
+
+def test_gym_make_builds_a_working_env(tmp_path):
+    """gym.make('D2DEnv-v0', env_config=...) through a stand-in `gym` package (tests/gym_stub_util.py): registration at
+    import (gym_d2d/__init__.py:8-11), a gym.Env subclass, reset / step with the reference's dict conventions."""
+    from pathlib import Path
+    from gym_stub_util import run_gym_make
+    out = run_gym_make(tmp_path, Path(__file__).resolve().parent.parent)
+    assert out['entry_point'] == 'gym_d2d_amd.envs:D2DEnv' and out['make'] == 'ok' and out['is_gym_env'] is True
+    assert out['agents'] == 7 and out['obs_width'] == 42 and out['obs_space'] == [42] and out['done'] == {'__all__': False}
+    assert out['info_keys'] == ['capacity_mbps', 'rate_bps', 'rb', 'sinr_db', 'snr_db', 'tx_pwr_dbm']
+
+
+def test_vec_env_obs_dtype_and_export_switch(native):
+    """env_config['obs_dtype'] = 'float64' returns the reference's observation dtype (obs_fn.py:51) with the float32 values;
+    export_actions=False leaves info['rb'] / info['tx_pwr_dbm'] out and every other output unchanged."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    cfg = {'num_rbs': 6, 'num_cues': 5, 'num_due_pairs': 9}
+    a = VecD2DEnv(dict(cfg), num_envs=32)
+    b64 = VecD2DEnv(dict(cfg, obs_dtype='float64'), num_envs=32, export_actions=False)
+    oa, ob = a.reset(seed=3), b64.reset(seed=3)
+    assert oa.dtype == torch.float32 and ob.dtype == torch.float64 and torch.equal(oa.double(), ob)
+    act = torch.randint(0, 6 * 21, (32, 14), device=a.device, dtype=torch.int32)
+    ra, rb_ = a.step(act), b64.step(act)
+    assert rb_[0].dtype == torch.float64 and torch.equal(ra[0].double(), rb_[0]) and torch.equal(ra[1], rb_[1])
+    assert rb_[3]['rb'] is None and rb_[3]['tx_pwr_dbm'] is None and ra[3]['rb'] is not None
+    assert torch.equal(ra[3]['sinr_db'], rb_[3]['sinr_db']) and torch.equal(ra[2], rb_[2])
+    with pytest.raises(ValueError):
+        VecD2DEnv(dict(cfg, obs_dtype='float16'), num_envs=2)
+    a.close(); b64.close()

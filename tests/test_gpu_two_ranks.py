@@ -1,5 +1,5 @@
-"""Two RANKS, each stepping its own env shard with the HIP library, gathered by StepGatherer on the GPU - on ONE device:
-both processes use cuda:0 and the gloo backend carries the collectives (RCCL refuses two ranks on one GPU, and the GPU box
+"""Two - and EIGHT, BASELINE config 5's rank count - RANKS, each stepping its own env shard with the HIP library, gathered by
+StepGatherer on the GPU - on ONE device: all processes use cuda:0 and the gloo backend carries the collectives (RCCL refuses two ranks on one GPU, and the GPU box
 has one).  What this exercises that the CPU gloo test cannot: real d2d_step outputs per rank (first_env offsets, counter-
 based reset), the CUDA side-stream / event choreography of StepGatherer, and the consumer-side d2d_expand_table - all
 compared with ONE process stepping the whole batch."""
@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 CFG = {'num_rbs': 6, 'num_cues': 5, 'num_due_pairs': 9}
-B_LOCAL, WORLD, STEPS = 24, 2, 3
+B_GLOBAL, STEPS = 48, 3
 
 
 def _free_port():
@@ -25,11 +25,11 @@ def _free_port():
 
 def _actions(step, first, count):
     rng = np.random.default_rng(1000 + step)
-    whole = np.concatenate([rng.integers(0, 6 * 24, (B_LOCAL * WORLD, 5)), rng.integers(0, 6 * 21, (B_LOCAL * WORLD, 9))], 1)
+    whole = np.concatenate([rng.integers(0, 6 * 24, (B_GLOBAL, 5)), rng.integers(0, 6 * 21, (B_GLOBAL, 9))], 1)
     return whole[first:first + count].astype(np.int32)
 
 
-def _rank(rank, port, out_dir):
+def _rank(rank, world, port, out_dir):
     for p in (str(ROOT), str(ROOT / 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,8 +38,8 @@ def _rank(rank, port, out_dir):
     import torch.distributed as dist
     from gym_d2d_amd.distributed import StepGatherer, expand_table, shard_range
     from gym_d2d_amd.envs import VecD2DEnv
-    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
-    first, end = shard_range(B_LOCAL * WORLD, WORLD, rank)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    first, end = shard_range(B_GLOBAL, world, rank)
     env = VecD2DEnv(dict(CFG), num_envs=end - first, first_env=first)
     dev = env.device
     obs = env.reset(seed=99)
@@ -54,6 +54,18 @@ def _rank(rank, port, out_dir):
         torch.cuda.synchronize()
         outs.append((rewards.cpu().numpy().copy(), table.cpu().numpy().copy(),
                      expand_table(table, env.simulator.handle).cpu().numpy().copy()))
+    # the compact-obs plan on the same streams: rewards only, and the observation columns on every 2nd launch
+    g2 = StepGatherer(end - first, 14, dev, mode='rewards')
+    g3 = StepGatherer(end - first, 14, dev, signal_every=2)
+    g3.gather_positions(env._t['table'])
+    for k in range(STEPS):
+        env.step(torch.as_tensor(_actions(k, first, end - first), device=dev))
+        g2.launch(env._t['reward']); g3.launch(env._t['reward'], env._t['table'])
+        r2, s2 = g2.wait()
+        r3, s3 = g3.wait()
+        torch.cuda.synchronize()
+        assert s2 is None and np.array_equal(r2.cpu().numpy(), outs[k][0]) and np.array_equal(r3.cpu().numpy(), outs[k][0])
+        assert g3.signal_step == (k // 2) * 2 and np.array_equal(g3.table().cpu().numpy(), outs[(k // 2) * 2][1])
     if rank == 0:
         np.savez(Path(out_dir) / 'gathered.npz', **{f'{name}{k}': arr for k, o in enumerate(outs)
                                                     for name, arr in zip(('reward', 'table', 'obs'), o)})
@@ -62,16 +74,17 @@ def _rank(rank, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_one_gpu_reproduce_the_single_process_batch(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_ranks_sharing_one_gpu_reproduce_the_single_process_batch(tmp_path, world):
     import torch
     import torch.multiprocessing as mp
     from gym_d2d_amd.envs import VecD2DEnv
-    mp.spawn(_rank, args=(_free_port(), str(tmp_path)), nprocs=WORLD, join=True)
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / 'gathered.npz')
-    env = VecD2DEnv(dict(CFG), num_envs=B_LOCAL * WORLD)
+    env = VecD2DEnv(dict(CFG), num_envs=B_GLOBAL)
     env.reset(seed=99)
     for k in range(STEPS):
-        obs, rew, dones, info = env.step(torch.as_tensor(_actions(k, 0, B_LOCAL * WORLD), device=env.device))
+        obs, rew, dones, info = env.step(torch.as_tensor(_actions(k, 0, B_GLOBAL), device=env.device))
         torch.cuda.synchronize()
         # sharding changes nothing: positions and reset actions are keyed by global env index, steps are per env
         assert np.array_equal(got[f'reward{k}'], rew[:, 0].cpu().numpy()), k
@@ -97,6 +110,12 @@ def test_bench_two_ranks_on_one_gpu_agree_with_one_rank_of_twice_the_envs():
     assert two['n_gpus'] == 2 and two['rccl_ranks'] == 2 and two['allreduce_rank_count'] == 2.0
     assert two['allgather_envs'] == 128 and two['checksums_agree'] is True and 'shared_gpu' in two
     assert two['status_flags'] == 0
+    # the fields that make a first real SCALE line self-explaining
+    assert abs(two['value_per_gpu'] * 2 - two['value']) < 1e-6 * two['value'] and len(two['per_rank']) == 2
+    g = two['gather']
+    assert g['mode'] == 'table' and g['bytes_per_gpu_per_step'] == 64 * 4 + 64 * 50 * 2 * 4 and g['gather_ms_per_step'] > 0
+    assert g['ms_per_step_without_gather'] > 0 and 'gather_exposed_ms' in g
+    assert all(r['step_kernel_ms'] > 0 for r in two['per_rank'])
     one = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '1', '--force-dist', '--workload', 'default',
                           '--obs', 'table', '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-single-env-latency'],
                          capture_output=True, text=True, timeout=600,

@@ -34,6 +34,7 @@ class RecordingHandle:
     def set_reward(self, rid, param=0.0): self._rec('reward', rid, param)
     def set_obs_mode(self, m): self._rec('obs_mode', m)
     def set_env_offset(self, k): self._rec('env_offset', k)
+    def set_export_actions(self, on): self._rec('export_actions', on)
     def set_stream(self, p): self._rec('stream', p)
     def reset_positions(self, seed, episode=0, mask=None, xy=None): self._rec('reset', seed, episode, mask, xy)
     def set_positions(self, x, y, env_begin=0): self._rec('positions', np.asarray(x), np.asarray(y))

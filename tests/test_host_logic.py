@@ -37,6 +37,19 @@ def test_product_path_fails_loudly_without_gpu():
         D2DEnv({})
 
 
+def test_gym_make_registration_is_executed(tmp_path):
+    """gym_d2d/__init__.py:8-11: `register(id='D2DEnv-v0', entry_point=...:D2DEnv)` at import, `gym.make('D2DEnv-v0',
+    env_config=...)` as the factory.  gym is not installed here: a child process gets a stand-in `gym` on its path, imports
+    this package (which must then take its gym branch) and calls gym.make - which reaches D2DEnv.__init__: a working env on a
+    GPU box (tests/test_gpu_round3.py runs the same child there), the loud NativeError without one."""
+    from gym_stub_util import run_gym_make
+    out = run_gym_make(tmp_path, ROOT)
+    assert out['have_gym'] is True and out['space_is_gym'] is True
+    assert out['entry_point'] == 'gym_d2d_amd.envs:D2DEnv'
+    import torch
+    assert out['make'] == ('ok' if torch.cuda.is_available() else 'NativeError')
+
+
 def test_product_package_never_imports_the_oracle():
     for path in (ROOT / 'gym_d2d_amd').rglob('*.py'):
         text = path.read_text()

@@ -39,7 +39,7 @@ def prepare(names):
         print('built', out.name)
 
 
-def one(lib, workload):
+def one(lib, workload, export=True):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools'))
     from gym_d2d_amd import _native
     _native.LIB_PATH = Path(lib).resolve()
@@ -57,15 +57,17 @@ def one(lib, workload):
         cols = p
     env.reset(seed=1)
     h = env.simulator.handle
+    h.set_export_actions(export)
     act = torch.randint(0, r * 21, (64, b, cols), device=env.device, dtype=torch.int32)
     t = [timed(h, act, 32) for _ in range(15)]
-    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
+    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'export_rb_pwr': int(export), 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
 
 
-def run(workload, passes):
+def run(workload, passes, export=True):
     for k in range(passes):
         for lib in sorted(LIBS.glob('*.so')):
-            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload], capture_output=True, text=True)
+            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload] + ([] if export else ['--no-export']),
+                               capture_output=True, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             print(line[-1] if line else f'{lib.name}: failed {r.stderr[-300:]}', flush=True)
 
@@ -76,10 +78,11 @@ if __name__ == '__main__':
     ap.add_argument('names', nargs='*')
     ap.add_argument('--workload', default='stress')
     ap.add_argument('--passes', type=int, default=2)
+    ap.add_argument('--no-export', action='store_true', help='d2d_set_export_actions(0): no decoded rb / pwr planes')
     a = ap.parse_args()
     if a.what == 'prepare':
         prepare(a.names)
     elif a.what == 'run':
-        run(a.workload, a.passes)
+        run(a.workload, a.passes, not a.no_export)
     else:
-        one(a.names[0], a.workload)
+        one(a.names[0], a.workload, not a.no_export)

@@ -62,12 +62,13 @@ def stress(args):
     env.reset(seed=1)
     h = env.simulator.handle
     act = torch.randint(0, r * 21, (64, b, c + p), device=env.device, dtype=torch.int32)      # fresh actions per launch
-    # (reward fn, search variant, decoded rb / pwr exported).  'two_per_rb' runs the lists on actions that put exactly two
-    # links on every RB: no list ever overflows, no lane of a wave has more members than another
-    variants = [(rw, name, ex) for rw in ((1, 0, 2) if args.quick else (1, 0, 2, 3))
-                for name in ('mask_walk_nested', 'member_lists') + (() if args.quick else ('mask_walk_flat', 'all_pairs'))
-                for ex in ((1, 0) if rw == 1 and name in ('mask_walk_nested', 'member_lists') else (1,))]
-    variants += [(1, 'member_lists_two_per_rb', 1), (1, 'mask_walk_two_per_rb', 1)]
+    # (reward fn, variant, decoded rb / pwr exported).  Rollout-kernel options: scalar record loads (srec), nontemporal result
+    # stores (nt); search variants: mask walk (default), member lists (generic kernel), all-pairs sweep.  'two_per_rb' = actions
+    # that put exactly two links on every RB (no imbalance between the lanes of a wave).
+    variants = [(1, name, ex) for name in ('plain', 'srec', 'nt', 'srec_nt') for ex in (1, 0)]
+    if not args.quick:
+        variants += [(rw, name, 1) for rw in (0, 2, 3) for name in ('srec_nt', 'member_lists', 'mask_walk_flat')]
+        variants += [(1, 'member_lists', 1), (1, 'all_pairs', 1), (1, 'srec_nt_two_per_rb', 1)]
     pc, pd = env.num_pwr_actions['cue'], env.num_pwr_actions['due']
     two = torch.cat([torch.arange(c, device=env.device, dtype=torch.int32) * pc + 3,
                      torch.arange(p, device=env.device, dtype=torch.int32) * pd + 5])[None, None].expand(64, b, c + p).contiguous()
@@ -80,6 +81,8 @@ def stress(args):
             h.set_bucketing(v[1] != 'all_pairs')
             h.set_export_actions(bool(v[2]))
             h.set_tuning(_native.TUNE_STEP_WALK, 1 if v[1] == 'mask_walk_flat' else (2 if v[1].startswith('member_lists') else 0))
+            h.set_tuning(_native.TUNE_STEP_SCALAR_RECORDS, int('srec' in v[1]))
+            h.set_tuning(_native.TUNE_STEP_NT_RESULTS, int('nt' in v[1]))
             times[v].append(timed(h, two if v[1].endswith('two_per_rb') else act, 32 if v[1] != 'all_pairs' else 8))
     h.set_export_actions(True)
     bytes_per = b * (c + p) * 64.0
@@ -89,6 +92,26 @@ def stress(args):
               'min_us': round(min(times[v]), 2), 'algorithmic_GBps': round(bytes_per / med / 1e3), 'rounds': len(times[v])},
              args.out)
     env.close()
+
+
+def scale(args):
+    """Steady state vs ramp: the same step at 1024 ... 16384 envs x 512 links, compact-obs mode.  A launch of B envs costs
+    t(B) = t0 + B / rate: the slope is the sustained rate, t0 what launching, the first loads and the last stores' drain cost."""
+    c, p, r = 256, 256, 256
+    for b in (1024, 2048, 4096, 8192, 16384):
+        env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
+        env.reset(seed=1)
+        h = env.simulator.handle
+        act = torch.randint(0, r * 21, (max(8, 65536 // b), b, c + p), device=env.device, dtype=torch.int32)
+        for export in (1, 0):
+            h.set_export_actions(bool(export))
+            t = [timed(h, act, 32) for _ in range(args.rounds)]
+            med = statistics.median(t)
+            emit({'sweep': 'stress_scale_envs', 'envs': b, 'export_rb_pwr': export, 'median_us': round(med, 2), 'min_us': round(min(t), 2),
+                  'us_per_4096_envs': round(med * 4096 / b, 2), 'algorithmic_GBps': round(b * (c + p) * 64.0 / med / 1e3)}, args.out)
+        env.close()
+        del env, act
+        torch.cuda.empty_cache()
 
 
 def ablate(args):
@@ -179,9 +202,9 @@ def wall(args):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['stress', 'default', 'wall', 'ablate'])
+    ap.add_argument('what', choices=['stress', 'default', 'wall', 'ablate', 'scale'])
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--quick', action='store_true', help='stress: only the mask walk and the member lists')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
-    {'stress': stress, 'default': default, 'wall': wall, 'ablate': ablate}[a.what](a)
+    {'stress': stress, 'default': default, 'wall': wall, 'ablate': ablate, 'scale': scale}[a.what](a)
