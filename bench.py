@@ -287,6 +287,8 @@ def parse_args(argv=None):
                     help='N = 1 also times the drop-in single-env D2DEnv.step (host dicts in / out); this skips it')
     ap.add_argument('--no-extras', action='store_true',
                     help='N = 1, default run: skip other_workloads / vec_env_step_ms / the write-ceiling probe (the headline only)')
+    ap.add_argument('--no-export', action='store_true',
+                    help='d2d_set_export_actions(0) for the measured session: no decoded (rb, pwr) planes (a rollout knows its actions)')
     ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,fuse,walk')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST HOOK: no GPU, gloo backend, synthetic per-rank results - exercises only the launcher / gather plumbing')
@@ -312,6 +314,7 @@ class Session:
     def __init__(self, torch, args, key, obs, dev, rank, local, steps, warmup, *, envs=0, cue_mode='', tune='', stub=False,
                  export=True):
         self.torch, self.args, self.key, self.obs, self.dev, self.rank, self.stub = torch, args, key, obs, dev, rank, stub
+        self.export = export
         w = dict(WORKLOADS[key])
         if envs:
             w['envs'] = envs
@@ -450,6 +453,7 @@ class Session:
                 'reward_fn': 'SystemCapacity',
                 'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else 'LogDistance(ple=2)',
                 'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
+                'decoded_rb_pwr_export': 'on' if self.export else 'off (d2d_set_export_actions(0))',
                 'cue_actions': self.cue_mode + (' (UplinkTrafficModel round-robin, held in the kernel\'s link records; agents supply DUE actions only)'
                                                 if self.cue_mode == 'traffic' else ' (agents supply CUE and DUE actions)'),
                 'parallelism': f'env-shard x{world}' + gather_desc}
@@ -552,7 +556,7 @@ def worker(args):
             torch.cuda.synchronize(dev)
 
     sess = Session(torch, args, args.workload, args.obs, dev, rank, local, args.steps, args.warmup, envs=args.envs,
-                   cue_mode=args.cue_actions, tune=args.tune, stub=stub)
+                   cue_mode=args.cue_actions, tune=args.tune, stub=stub, export=not args.no_export)
     b, n = sess.b, sess.n
 
     def make_gatherer(mode, signal_every=1):

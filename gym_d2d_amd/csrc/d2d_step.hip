@@ -363,7 +363,7 @@ __device__ __forceinline__ void clear_masks(const Smem& s, int R, int W, int lt,
 // FULL = LPT > 0, one env per workgroup and N == LPT * blockDim: every lane owns exactly LPT links of an existing env, so
 //        no lane predication (exec-mask save / restore on the scalar pipe) is generated anywhere outside the walk.
 #define FOR_MY_LINKS(u, i)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < (LPT > 0 ? LPT : 0x7fffffff); ++u)                \
+    _Pragma("unroll UNROLL_LINKS") for (int u = 0; u < (LPT > 0 ? LPT : 0x7fffffff); ++u)  \
         if (const int i = lt + u * TPE; !(FULL || (active && i < N))) { if (LPT == 0) break; } else
 #define KEPT(u) (LPT > 0 ? (u) : 0)                /* register slot of link u (strided kernels keep only their first) */
 #define IN_REGS(u) (LPT > 0 || (u) == 0)
@@ -375,6 +375,9 @@ __device__ __forceinline__ void clear_masks(const Smem& s, int R, int W, int lt,
 #endif
 #define ABL(bit) (D2D_STEP_ABLATE && (a.ablate & (bit)))
 // branch weights: block placement moves the rare arms (invalid actions, all-pairs sweep, flag reporting) behind the hot path
+// rare arms (a reward rule's search when it fires, the sweep fallbacks): LLVM's loop vectoriser otherwise unrolls and widens
+// them into hundreds of instructions whose live values spill the hot path's scalars
+#define COLD_LOOP _Pragma("clang loop vectorize(disable) interleave(disable) unroll(disable)")
 #define LIKELY(x) __builtin_expect(!!(x), 1)
 #define UNLIKELY(x) __builtin_expect(!!(x), 0)
 // diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py)
@@ -404,12 +407,15 @@ __device__ __forceinline__ void clear_masks(const Smem& s, int R, int W, int lt,
 template <int MODE, int LPT, bool FULL, int HOT = 0, int OPT = 0>
 __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr int KEEP = LPT > 0 ? LPT : 1;
+    constexpr int UNROLL_LINKS = LPT > 0 ? LPT : 1;                // strided kernels: the per-link bodies are not unrolled
     constexpr bool LISTS = (OPT & OPT_LISTS) != 0, SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0;
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
     const int cfg_col_mode = HOT ? 0 : a.col_mode;
     const int cfg_reward_fn = HOT ? 1 : a.reward_fn;
     const int cfg_write_table = HOT ? 1 : a.write_table;
-    const int cfg_walk = (HOT || LISTS) ? 0 : a.walk;
+    // (the flattened walk is an A/B shape of the power-law kernels: the table / shadowing kernels, whose pair evaluation is
+    // hundreds of instructions, carry the nested one only)
+    const int cfg_walk = (HOT || LISTS || MODE == PL_SHADOW || MODE == PL_TABLE) ? 0 : a.walk;
     const bool cfg_export_actions = a.rb_out != nullptr;          // the info dict's rb / tx_pwr_dbm (d2d_set_export_actions)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int N = a.N, R = a.R, D = a.D, W = a.mask_words, TPE = a.tpe;
@@ -808,9 +814,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         if (j != LIST_EMPTY && j != (unsigned)i) hit |= ((a.side_words[j >> 5] >> (j & 31u)) & 1u) != 0u;
                     }
                 } else if (use_masks) {
+                    COLD_LOOP
                     for (int w = 0; w < W; ++w)
                         hit |= (s.mask[(unsigned)w * (unsigned)R + (unsigned)rb] & a.side_words[w]) != 0u;
                 } else {
+                    COLD_LOOP
                     for (int k = 0; k < N; ++k)
                         hit |= (k != i) & ((HOT ? (a.rec_a[k].x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK : s.aux[k] >> 24) == LINK_SIDELINK) &
                                (__float_as_int(s.link[k].w) == rb);
@@ -871,7 +879,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float total = (float)tot * 2.3283064365386963e-10f;
                 const int viol = atomicOr(&s.flags[1], 0);
                 const float r = (viol & 1) ? -1.0f : ((viol & 4) ? __int_as_float(0x7FC00000) : ((viol & 2) ? __int_as_float(0x7F800000) : total * a.inv_n));
-                for (int k = lane; k < N; k += 64) ST(at(a.reward, fresh((row + (unsigned)k) * 4u)), r);
+                // N = LPT * blockDim is a multiple of 64: the row goes out as 16-byte stores
+                const f32x4 r4 = {r, r, r, r};
+                for (int k = lane * 4; k < N; k += 256) ST(reinterpret_cast<f32x4*>(at(a.reward, fresh((row + (unsigned)k) * 4u))), r4);
             }
             if (lane == 0) a.env_flags[b] = atomicOr(&s.flags[0], 0);
         }
@@ -916,6 +926,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                     }
                 }
             } else {
+                COLD_LOOP
                 for (int j = 0; j < N; ++j)
                     bad |= (j != i) & ((s.aux[j] >> 24) != LINK_SIDELINK) & (__float_as_int(s.link[j].w) == rbi) &
                            (s.sinr[j] < a.reward_param);

@@ -11,6 +11,10 @@ T is further split by how often it changes: its four position columns are consta
 gather carries only the (sinr_dB, snr_dB) columns [B_local, N, 2] - a third of the bytes (16.8 MB instead of 50 MB
 per GPU per step at 4096 x 512), which matters because a ring all-gather is bound by ONE xGMI link.
 
+Against the compact-obs step (about 30 us at 4096 x 512) even those 16.8 MB are forty steps' worth of ring time: StepGatherer
+then gathers rewards only (mode='rewards', 16 KB per GPU) and / or ships the (sinr, snr) columns on every K-th step
+(signal_every=K).
+
 The per-step gather runs on a side stream from a staging copy, so it overlaps the obs-expansion kernel and the next
 step; only the small device-to-device staging copy is ordered against the next step's writes.
 Backend "nccl" is RCCL on ROCm; "gloo" works for CPU tensors (used by the CPU tests).

@@ -43,6 +43,12 @@ def one(lib, workload, export=True):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools'))
     from gym_d2d_amd import _native
     _native.LIB_PATH = Path(lib).resolve()
+    # an older build lacks the newer entry points: drop them from the binding (this tool only) and make their wrappers no-ops
+    import ctypes
+    probe = ctypes.CDLL(str(_native.LIB_PATH))
+    for name in [n for n in _native.SIGNATURES if not hasattr(probe, n)]:
+        del _native.SIGNATURES[name]
+        setattr(_native.Handle, name[len('d2d_'):], lambda self, *a, **k: None)
     import torch
     from ab_step import timed
     from gym_d2d_amd.envs import VecD2DEnv

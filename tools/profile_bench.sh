@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for one bench workload, on the GPU box (counters and traces in SEPARATE runs):
-#   tools/profile_bench.sh <tag> <workload> <obs> [steps]      e.g.  tools/profile_bench.sh r2 stress linear 100
+#   tools/profile_bench.sh <tag> <workload> <obs> [steps] [extra bench args]     e.g.  tools/profile_bench.sh r3 stress table 100 --no-export
 # Writes raw output under gpurun_out/prof_<tag>_<workload>_<obs>/ and the condensed summaries into profiles/.
-tag=$1; wl=$2; obs=$3; steps=${4:-100}
+tag=$1; wl=$2; obs=$3; steps=${4:-100}; extra="${@:5}"
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_${tag}_${wl}_${obs}
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-args="--workload $wl --obs $obs --no-cpu-baseline --no-single-env-latency"
+args="--workload $wl --obs $obs --no-cpu-baseline --no-single-env-latency --no-extras $extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $R/bench.py $args --steps $steps --warmup 10 > $out/kt.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $R/bench.py $args --steps 5 --warmup 1 > $out/pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py $args --steps 5 --warmup 1 > $out/pmc_fetch.log 2>&1
