@@ -371,14 +371,18 @@ class Session:
         # over the same steps brackets GROUPS of back-to-back launches with one event pair (on the stream the kernels run
         # on): average launch duration = group time / launches, inter-launch gaps included.
         self.events_in_timed = self.obs == 'linear' and self.n > 128
+        self.raw_handle = obs == 'none'                  # VecD2DEnv has no obs-less mode: the handle's obs mode is switched under it
 
     def run(self, k0, k1, gatherer=None, with_reset=False):
+        """Steps k0 .. k1-1 through the PUBLIC batched API, VecD2DEnv.step(actions) -> (obs, rewards, dones, info) (the C-ABI
+        handle directly only where the session's obs mode was switched under the env: core_mode; and for the CPU stub)."""
         h, env, actions = self.h, self.env, self.actions
+        step = (lambda a: h.step(a.data_ptr())) if (self.stub or self.raw_handle) else env.step
         for k in range(k0, k1):
             new_episode = with_reset and k % 10 == 0
             if new_episode:                              # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
                 h.reset_positions(1234, k // 10)
-            h.step(actions[k].data_ptr())
+            step(actions[k])
             if gatherer is not None and (new_episode or k == 0):
                 gatherer.gather_positions(env._t['table'])      # position columns only change at reset (not per step)
             if gatherer is not None:
@@ -453,6 +457,7 @@ class Session:
                 'reward_fn': 'SystemCapacity',
                 'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else 'LogDistance(ple=2)',
                 'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
+                'api': 'C-ABI handle (d2d_step)' if (self.stub or self.raw_handle) else 'VecD2DEnv.step(actions) -> (obs, rewards, dones, info), the public batched API',
                 'decoded_rb_pwr_export': 'on' if self.export else 'off (d2d_set_export_actions(0))',
                 'cue_actions': self.cue_mode + (' (UplinkTrafficModel round-robin, held in the kernel\'s link records; agents supply DUE actions only)'
                                                 if self.cue_mode == 'traffic' else ' (agents supply CUE and DUE actions)'),
@@ -684,7 +689,7 @@ def core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer):
     _native, h, b, n = sess.native, sess.h, sess.b, sess.n
     h.set_obs_mode(_native.OBS_TABLE)
     saved_obs, saved_events = sess.obs, sess.events_in_timed
-    sess.obs, sess.events_in_timed = 'table', False
+    sess.obs, sess.events_in_timed, sess.raw_handle = 'table', False, True
     out = {}
     try:
         for export in (False, True):
@@ -711,7 +716,7 @@ def core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer):
     finally:
         h.set_export_actions(True)
         h.set_obs_mode(_native.OBS_LINEAR)
-        sess.obs, sess.events_in_timed = saved_obs, saved_events
+        sess.obs, sess.events_in_timed, sess.raw_handle = saved_obs, saved_events, False
     return out
 
 
@@ -723,6 +728,11 @@ def n1_extras(torch, args, dev, local, fence):
     # BASELINE.json configs[1]: 1024 x 50, traffic-model CUEs, LinearObs fused into the step launch
     s = Session(torch, args, 'default', 'linear', dev, 0, local, 200, 20)
     out['other_workloads']['default'] = summarise(s, s.timed(fence), 200)
+    try:                                                  # what a pure fill of about the same size reaches on this box (61 MB of obs per step)
+        small, _ = s.h.probe_write_variants(64 << 20, 20)
+        out['other_workloads']['default']['roofline']['box_ceiling_GBs_64MiB_bursts'] = small
+    except Exception as exc:                              # pragma: no cover
+        out['other_workloads']['default']['roofline']['box_ceiling_error'] = repr(exc)
     out['vec_env_step_ms']['default (config 2), LinearObs'] = s.vec_env_step_ms()
     s.close()
     # BASELINE.json configs[3]: FreeSpacePathLoss + a custom ObsFunction through the plugin ABI, 4096 x 512

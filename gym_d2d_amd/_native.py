@@ -26,7 +26,8 @@ OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
 FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
 (TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK, TUNE_OBS_VARIANT,
  TUNE_STEP_THREADS, TUNE_STEP_ENVS_PER_WG, TUNE_STEP_BLOCK, TUNE_STEP_FUSE_OBS, TUNE_STEP_ABLATE,
- TUNE_STEP_WALK, TUNE_STEP_PREFETCH, TUNE_STEP_LPT, TUNE_STEP_NT_RESULTS, TUNE_STEP_SCALAR_RECORDS) = range(15)
+ TUNE_STEP_WALK, TUNE_STEP_PREFETCH, TUNE_STEP_LPT, TUNE_STEP_NT_RESULTS, TUNE_STEP_SCALAR_RECORDS,
+ TUNE_STEP_OBS_ROTATE) = range(16)
 UNIQUE_ID_BYTES = 128
 
 BUFFER_DTYPES = {BUF_ACTIONS: np.int32, BUF_RB: np.int32, BUF_PWR: np.int32, BUF_ENV_FLAGS: np.int32}

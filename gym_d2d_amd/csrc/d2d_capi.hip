@@ -97,6 +97,7 @@ struct d2d_handle {
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
     int num_cus = 0;
     int tune_step_prefetch = -1;                     // action prefetch distance in envs: -1 auto, 0 off
+    int tune_step_obs_rotate = -1;                   // fused expansion start-phase multiplier: -1 auto (29), 0 off
     int tune_step_nt = -1, tune_step_srec = -1;      // nontemporal result stores / scalar record loads: -1 auto, 0 off, 1 on (if legal)
     int tune_step_epw = 0, tune_step_block = 0, tune_step_fuse = -1, tune_step_ablate = 0, tune_step_walk = -1, tune_step_lpt = -1;
     // d2d_step_host: packed device block + pinned host mirrors
@@ -354,8 +355,8 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.ablate = h->tune_step_ablate;
     s.dbg = nullptr;
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
-    if (h->tune_step_ablate & 8192) {          // phase stamps: [B workgroups][16 waves][8] u64 (tools/phase_times.py)
-        if (!h->dbg) HIP_TRY(hipMalloc(&h->dbg, (size_t)h->B * 16 * 8 * 8));
+    if (h->tune_step_ablate & 8192) {          // phase stamps: [B workgroups][16 waves][16] u64 (tools/phase_times.py)
+        if (!h->dbg) HIP_TRY(hipMalloc(&h->dbg, (size_t)h->B * 16 * 16 * 8));
         s.dbg = h->dbg;
     }
 #endif
@@ -420,6 +421,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     }
     s.tpe_magic = ((1u << 20) + (unsigned)tpe - 1) / (unsigned)tpe;
     if (fuse) {
+        s.obs_rotate = h->tune_step_obs_rotate >= 0 ? h->tune_step_obs_rotate : 29;
         s.obs_q_per_row = (unsigned)(6 * N / fuse);
         s.obs_q_magic = ((1ull << 40) + s.obs_q_per_row - 1) / s.obs_q_per_row;
     }
@@ -839,6 +841,10 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
             if (value != 0) return fail(D2D_ERR_UNSUPPORTED, "D2D_TUNE_STEP_ABLATE needs the diagnostic build (D2D_BUILD_DIAG=1 python -m gym_d2d_amd.build)");
             break;
 #endif
+        case D2D_TUNE_STEP_OBS_ROTATE:
+            if (value < -1 || value > 65535) return fail(D2D_ERR_INVALID, "obs_rotate must be in [-1, 65535]");
+            h->tune_step_obs_rotate = value;
+            break;
         case D2D_TUNE_STEP_NT_RESULTS:
             if (value < -1 || value > 1) return fail(D2D_ERR_INVALID, "nt_results must be -1, 0 or 1");
             h->tune_step_nt = value;

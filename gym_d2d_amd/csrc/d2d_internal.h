@@ -58,6 +58,7 @@ struct StepArgs {
     unsigned long long* dbg; // DIAGNOSTIC builds only: [workgroup][wave][8] shader-clock stamps at the phase boundaries, or null
     // fused LinearObs expansion (small N: one launch per step instead of two); 0 = off, else floats per store (2 | 4)
     int fuse_obs;
+    int obs_rotate;                  // fused expansion: workgroup w starts at step (w * obs_rotate) mod (its steps) of its (env, pass) sequence; 0 = all from the start
     unsigned obs_q_per_row;          // 6N / fuse_obs
     unsigned long long obs_q_magic;  // ceil(2^40 / obs_q_per_row)
     // inputs

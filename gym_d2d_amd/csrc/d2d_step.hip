@@ -383,7 +383,7 @@ __device__ __forceinline__ void clear_masks(const Smem& s, int R, int W, int lt,
 // diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py)
 #if D2D_STEP_ABLATE
 #define STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0)                                                              \
-        a.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+        a.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
@@ -940,6 +940,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 
     asm volatile("" ::"v"(pf));                    // consume the prefetched word (late)
     if (active && lt == 0) a.env_flags[b] = s.flags[0];
+    STAMP(7);
 
     // ---- pass 4 (small N only): LinearObs expansion of this workgroup's envs, obs_fn.py:43-53.  Every thread of the
     // workgroup streams 16-byte (or 8-byte, odd N) stores over the contiguous [N][6N] block of each env; tflat was
@@ -958,20 +959,29 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             const unsigned f0 = q * 4u, f1 = f0 + 2u;
             const unsigned t0 = f0 / 6u, t1 = f1 / 6u;       // by the compiler's multiply-shift: constants of the thread
             const bool own0 = f0 < 6u, own1 = f1 < 6u;
-            for (int el = 0; el < a.epw; ++el) {
-                const int be = blockIdx.x * a.epw + el;
-                if (be >= a.B) break;
-                const f32x2* t2 = reinterpret_cast<const f32x2*>(smem_raw + (unsigned)el * a.lds.env_bytes + a.lds.tflat);
-                f32x4* out = reinterpret_cast<f32x4*>(a.obs + (size_t)be * N * row_floats) + q;
-                if (worker)
-                    for (unsigned i = r; i < (unsigned)N; i += RP) {
-                        const unsigned head = 6u * i;
-                        const unsigned s0 = own0 ? head + f0 : (i >= t0 ? f0 - 6u : f0);
-                        const unsigned s1 = own1 ? head + f1 : (i >= t1 ? f1 - 6u : f1);
-                        const f32x2 lo = t2[s0 >> 1], hi = t2[s1 >> 1];
-                        const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
-                        __builtin_nontemporal_store(v, out + (size_t)i * q_per_row);
-                    }
+            // All workgroups are resident at once and reach this point together; each owns one contiguous region (epw envs x
+            // N rows).  Walked from its start by everyone, the chip's concurrent stores sit a fixed stride apart (one region)
+            // and, depending on where the allocation landed physically, pile onto a subset of the HBM channels (14.9 ... 17.4
+            // us per step for the SAME launch across allocations, tools/probes/context_effect.py).  So every workgroup starts
+            // at its own phase of the (env, pass) sequence and wraps around: the concurrent addresses are decorrelated.
+            const unsigned passes = ((unsigned)N + RP - 1u) / RP;
+            const unsigned n_el = min((unsigned)a.epw, (unsigned)a.B - blockIdx.x * (unsigned)a.epw);
+            const unsigned total_it = n_el * passes;
+            unsigned it0 = a.obs_rotate ? (blockIdx.x * (unsigned)a.obs_rotate) % total_it : 0u;
+            unsigned el = it0 / passes, ps = it0 - el * passes;
+            for (unsigned t = 0; t < total_it; ++t) {
+                const f32x2* t2 = reinterpret_cast<const f32x2*>(smem_raw + el * a.lds.env_bytes + a.lds.tflat);
+                f32x4* out = reinterpret_cast<f32x4*>(a.obs + (size_t)(blockIdx.x * (unsigned)a.epw + el) * N * row_floats) + q;
+                const unsigned i = r + ps * RP;
+                if (worker && i < (unsigned)N) {
+                    const unsigned head = 6u * i;
+                    const unsigned s0 = own0 ? head + f0 : (i >= t0 ? f0 - 6u : f0);
+                    const unsigned s1 = own1 ? head + f1 : (i >= t1 ? f1 - 6u : f1);
+                    const f32x2 lo = t2[s0 >> 1], hi = t2[s1 >> 1];
+                    const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+                    __builtin_nontemporal_store(v, out + (size_t)i * q_per_row);
+                }
+                if (++ps == passes) { ps = 0u; if (++el == n_el) el = 0u; }
             }
         } else if (HOT != 2) {
             for (int el = 0; el < a.epw; ++el) {
@@ -997,6 +1007,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             }
         }
     }
+    STAMP(8);
 }
 
 // OR-reduction of the per-env flag words, run only when the host asks (d2d_status_flags): keeps the memset +
@@ -1056,7 +1067,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
-                      a.walk == 0 && a.prefetch_envs > 0 && a.ablate == 0 && a.mask_words > 0 &&
+                      a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 && a.mask_words > 0 &&
                       a.fuse_obs == 4 && a.obs_q_per_row > 0 && (unsigned)block_threads / a.obs_q_per_row >= 1u &&
                       (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \

@@ -193,6 +193,9 @@ typedef enum d2d_tuning {
                                       no consistent gain measured)                                             */
     D2D_TUNE_STEP_SCALAR_RECORDS = 14, /* rollout kernel: link records by one scalar load per wave when every aligned
                                       group of 64 links has identical records; -1 = auto (on when legal), 0 off  */
+    D2D_TUNE_STEP_OBS_ROTATE = 15, /* fused LinearObs expansion: workgroup w starts at step (w * value) mod (its steps) of
+                                      its (env, pass) store sequence and wraps, so that the concurrent stores of the
+                                      resident workgroups are not one fixed stride apart; -1 = auto (29), 0 = off  */
     D2D_TUNE_STEP_ABLATE = 9,      /* DIAGNOSTIC builds only (D2D_BUILD_DIAG=1), the one key that DOES change
                                       results: bit mask of kernel parts to skip (1 interferer walk, 2 mask
                                       build, 4 mask clear, 8 result stores, 16 table store, 32 rb/pwr stores,

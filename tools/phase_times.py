@@ -54,12 +54,12 @@ def main():
     h.step(act[7].data_ptr())
     torch.cuda.synchronize()
     waves = (c + p) // 64
-    raw = np.zeros((b, 16, 8), dtype=np.uint64)
+    raw = np.zeros((b, 16, 16), dtype=np.uint64)
     lib = h._lib
     lib.d2d_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.d2d_debug_stamps.restype = C.c_int
     assert lib.d2d_debug_stamps(h._h, raw.ctypes.data_as(C.c_void_p), raw.nbytes) == 0
-    st = raw.reshape(-1, 8)[: b * waves].reshape(b, waves, 8).astype(np.int64)
+    st = raw.reshape(-1, 16)[: b * waves, :8].reshape(b, waves, 8).astype(np.int64)
     # every XCD counts on its own base: workgroup g runs on XCD g % 8 (round-robin dispatch) -> normalise per XCD
     for x in range(8):
         st[x::8] -= st[x::8, :, 0].min()
