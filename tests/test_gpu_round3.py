@@ -45,7 +45,7 @@ def _snapshot(sim, native, with_obs=False):
 def _variants(native, h, fn):
     """fn() once per interferer-search variant; returns {name: snapshot}."""
     out = {}
-    for name, bucket, walk in (('mask_walk', True, 0), ('member_lists', True, 2), ('all_pairs', False, 0)):
+    for name, bucket, walk in (('mask_walk', True, 0), ('member_lists', True, 2), ('all_pairs', False, 0), ('auto', True, -1)):
         h.set_bucketing(bucket)
         h.set_tuning(native.TUNE_STEP_WALK, walk)
         out[name] = fn()
