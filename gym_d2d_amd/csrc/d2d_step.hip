@@ -16,27 +16,28 @@
 // Design (environments are independent): a workgroup owns `epw` environments, `tpe` threads each
 // (thread = link); at N = 512 that is one env per 512-thread workgroup, at N = 50 several 64-thread envs share one.
 //   * every per-link input is ONE coalesced, independent load: the link's (tx_x, tx_y, rx_x, rx_y) row (built once per
-//     reset, launch_link_positions), its action, and three 16-byte rows of the host-built link record (L2-resident);
-//     10^(p/10) is computed (v_exp_f32 with an exact hi/lo exponent split), so nothing in the prologue is a dependent
-//     second hop;
+//     reset, launch_link_positions), its action, and three 16-byte rows of the host-built link record (L2-resident; ONE
+//     scalar load per row and wave in the rollout kernel when the host found the records uniform within every group of 64
+//     links); 10^(p/10) is computed (v_exp_f32 with an exact hi/lo exponent split), so nothing in the prologue is a
+//     dependent second hop;
 //   * every link's transmitter tuple (tx_x, tx_y, effective tx power in mW, rb | index) is staged in LDS as a float4,
 //     so the interference loop is one ds_read_b128 per candidate interferer;
 //   * same-RB interferers (Actions.get_actions_by_rb) are found through per-RB membership bitmasks in LDS
 //     (R x ceil(N/32) u32 words built with ds_or_b32 - order independent - plus one summary word per RB naming its
-//     non-empty words) and walked in ascending link order with ctz in ONE flattened loop (a lane either fetches its
-//     next non-empty word or consumes a member).  A masked all-pairs sweep is the fallback (rb outside [0,R), N > 1024,
-//     or mask table too large).  Both visit interferers in ascending link index through the same fmaf, hence produce
-//     identical bits.  The stable counting sort by RB that north_star suggests (mask-popcount ranks + a wave scan of the
-//     per-RB counts, each receiver then streaming one contiguous LDS segment) was built and measured in round 2: its
-//     walk is cheaper (3.8 vs 8.3 us at 4096 x 512) but rank + scan + scatter + two more barriers cost 7 us, 40.0 vs
-//     35.3 us overall (profiles/r2_ab_step_variants_stress.jsonl, commit 'A/B evidence'); the bitmask walk stayed;
-//   * the kernel is bound by instruction issue (scalar pipe: one SALU per cycle per CU) and LDS bank conflicts, not by
-//     HBM latency (profiles/r2_ablation_step_kernel_stress.jsonl): the FULL specialisation (every lane owns a link, one
-//     env per workgroup) carries no lane predication, the LDS layout is computed on the host, and loops are flat;
+//     non-empty words) and walked in ascending link order with ctz: non-empty words outside, members inside, the next
+//     word requested before the current one's members are consumed.  Beyond 1024 links per env (the summary word's reach)
+//     per-RB member lists take over (slot counter + eight u16 slots per RB, sorted in registers by the receiver).  A masked
+//     all-pairs sweep is the fallback (rb outside [0,R), nothing fits in LDS, a list overflows where no masks exist).  All
+//     of them visit interferers in ascending link index through the same fmaf, hence produce identical bits.  Measured
+//     and rejected, with the evidence under profiles/: a stable counting sort by RB (r2: 40.0 vs 35.3 us), a flattened
+//     walk, the member lists in the rollout kernel (r3: 31.7 vs 30.8 us - the walk is not what paces the kernel);
+//   * what paces the kernel is the memory pipeline: bytes and vector-memory requests (dropping the optional decoded
+//     (rb, pwr) planes: -2.3 us; record rows by scalar loads: -2 us; one more prefetch load per lane: +1 us), not LDS
+//     latency chains, store-instruction counts or the walk's imbalance (profiles/r3_ab_*.jsonl);
 //   * all arithmetic is in the LINEAR domain (mW): sinr = S / (I + N) with one 10*log10 at the end; the literal
 //     dB-domain transcription cannot hold 1e-5 relative in fp32 (hard parts);
-//   * reductions (capacity sum) are xor-butterfly wave reductions + a fixed-order cross-wave sum:
-//     run-to-run deterministic.
+//   * the capacity sum is a DPP wave reduction + an order-independent cross-wave sum (32.32 fixed point in the barrier-free
+//     epilogue of the one-env-per-workgroup kernels, a fixed-order float sum elsewhere): run-to-run deterministic.
 #include "d2d_internal.h"
 #include <type_traits>
 

@@ -38,7 +38,8 @@ def scenarios(draw):
     n_over = draw(st.integers(0, 3))
     use_downlinks = draw(st.booleans()) and cues > 0
     explicit = draw(st.booleans())
-    return dict(big=big, rbs=rbs, cues=cues, dues=dues, envs=envs, seed=seed, model=model, ple=ple, reward=reward,
+    walk = draw(st.sampled_from([-1, 0, 1, 2]))       # interferer search: auto / mask walk nested / flattened / member lists
+    return dict(walk=walk, big=big, rbs=rbs, cues=cues, dues=dues, envs=envs, seed=seed, model=model, ple=ple, reward=reward,
                 reward_param=reward_param, n_over=n_over, use_downlinks=use_downlinks, explicit=explicit)
 
 
@@ -135,6 +136,7 @@ def test_random_scenarios_match_oracle(tmp_path_factory, sc):
     pwr = rng.integers(0, p_levels[None, :], (envs, n))
     h = sim.handle
     h.set_obs_mode(_native.OBS_LINEAR)
+    h.set_tuning(_native.TUNE_STEP_WALK, sc['walk'])
     h.set_reward(sc['reward'], sc['reward_param'])
     if sc['explicit']:
         sim.step_arrays(rb=rb, pwr=pwr)

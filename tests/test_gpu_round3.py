@@ -333,3 +333,47 @@ def test_vec_env_obs_dtype_and_export_switch(native):
     with pytest.raises(ValueError):
         VecD2DEnv(dict(cfg, obs_dtype='float16'), num_envs=2)
     a.close(); b64.close()
+
+
+def test_maximum_links_per_env_against_the_c_oracle(native):
+    """D2D_MAX_LINKS = 2048 links per env (1024 CUEs + 1024 DUE pairs: two links per thread, member lists by default because
+    the masks stop at 1024 links) - every link of every env against the plain-C oracle, for a spread-out RB choice (lists)
+    and a crowded one (64 RBs: 32 links per RB overflow every list -> the sweep)."""
+    from oracle import c_oracle
+    for rbs in (1024, 64):
+        b, cues, dues = 6, 1024, 1024
+        sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=rbs)
+        h = sim.handle
+        h.set_obs_mode(native.OBS_TABLE)
+        sim.step_arrays(raw)
+        got = _snapshot(sim, native)
+        assert (got['BUF_ENV_FLAGS'] == 0).all()
+        tx, rx, ty = default_links(cues, dues)
+        ref = c_oracle.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(*orc.device_configs(cues, dues)[1:]),
+                                 orc.PathLossSpec(), with_obs=False, threads=min(8, c_oracle.max_threads()))
+        assert np.array_equal(got['BUF_RB'], ref['rb']) and np.array_equal(got['BUF_PWR'], ref['pwr'])
+        for buf, f in (('BUF_SINR_DB', 'sinr_db'), ('BUF_SNR_DB', 'snr_db'), ('BUF_RATE_BPS', 'rate_bps'), ('BUF_CAPACITY', 'capacity_mbps')):
+            assert rel_err(got[buf], ref[f]) <= TOL, (rbs, f)
+        assert rel_err(got['BUF_REWARD'][:, 0], ref['reward']) <= TOL and rel_err(got['BUF_OBS_TABLE'], ref['table']) <= TOL
+        h.set_bucketing(False)                             # the all-pairs sweep: the same bits
+        sim.step_arrays(raw)
+        for buf, r in _snapshot(sim, native).items():
+            assert np.array_equal(got[buf], r), (rbs, buf)
+        sim.handle.close()
+    from gym_d2d_amd.simulator import Simulator
+    with pytest.raises(Exception):                          # one link more than the library takes
+        s = Simulator(dict(num_rbs=4, num_cues=1025, num_due_pairs=1024, num_envs=1))
+        s.set_links(s.default_link_keys())
+
+
+def test_write_ceiling_probe_family(native):
+    """d2d_probe_write_variants: every variant reports a plausible rate, the best is the maximum, the obs kernel's own
+    geometry is variant 0, and d2d_probe_write_bandwidth returns the same kind of figure."""
+    h = native.Handle(num_envs=8, num_rbs=4, num_cues=4, num_due_pairs=4, pwr_levels_due=21, pwr_levels_cue=24, pwr_levels_mbs=47)
+    best, rates = h.probe_write_variants(1 << 30, 3)
+    assert len(rates) == 33 and all(500.0 < r < 8000.0 for r in rates), rates
+    assert abs(best - max(rates)) < 1e-6
+    assert 500.0 < h.probe_write_bandwidth(1 << 30, 3) < 8000.0
+    with pytest.raises(native.NativeError):
+        h.probe_write_bandwidth(1 << 20, 1)                 # below one group of regions
+    h.close()
