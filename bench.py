@@ -448,8 +448,11 @@ class Session:
                                      'library stream, in a second pass over the same steps; the timed region itself runs '
                                      'without events')})
         if not self.stub:
-            attach_traffic(roof, self.key, self.obs, bool(self.args.envs))
+            attach_traffic(roof, self.key, self.obs, bool(self.args.envs), self.current_export())
         return roof
+
+    def current_export(self):
+        return getattr(self, 'export_now', self.export)
 
     def config(self, world, gather_desc=''):
         w = self.w
@@ -694,6 +697,7 @@ def core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer):
     try:
         for export in (False, True):
             h.set_export_actions(export)
+            sess.export_now = export
             gatherer = make_gatherer('rewards') if use_dist else None
             t = sess.timed(fence, gatherer)
             dt = t['dt']
@@ -715,6 +719,7 @@ def core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer):
                 out['with_decoded_rb_pwr_export'] = {k: entry[k] for k in ('value', 'ms_per_step', 'roofline')}
     finally:
         h.set_export_actions(True)
+        sess.export_now = sess.export
         h.set_obs_mode(_native.OBS_LINEAR)
         sess.obs, sess.events_in_timed, sess.raw_handle = saved_obs, saved_events, False
     return out
@@ -761,7 +766,7 @@ def n1_extras(torch, args, dev, local, fence):
     return out
 
 
-def attach_traffic(roof, workload, obs, custom_envs):
+def attach_traffic(roof, workload, obs, custom_envs, export=True):
     """HBM bytes per launch come from rocprofv3 PMC passes, which cannot be collected from inside this process: the
     figure is QUOTED from the newest committed summary for this kernel and workload, and only if that summary was
     made from the SAME kernel sources that are running now (digest of csrc/ recorded by tools/summarize_profiles.py);
@@ -777,6 +782,8 @@ def attach_traffic(roof, workload, obs, custom_envs):
             continue
         if rec.get('workload_key') != f'{workload}/{obs}':
             continue
+        if obs != 'linear' and ('--no-export' in rec.get('command', '')) == bool(export):
+            continue            # collected with / without the decoded (rb, pwr) planes: 8 bytes per link apart
         for kname, d in rec.get('kernels', {}).items():
             if roof['kernel'].split(' ')[0] in kname and 'hbm_bytes_per_launch' in d:
                 if rec.get('source_digest') == digest:

@@ -14,4 +14,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/b
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $out/pmc_sq1 -- python3 $R/bench.py $args --steps 5 --warmup 1 > $out/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $out/pmc_sq2 -- python3 $R/bench.py $args --steps 5 --warmup 1 > $out/pmc_sq2.log 2>&1
 cd $R
-python3 tools/summarize_profiles.py $tag $wl $obs $out
+python3 tools/summarize_profiles.py $tag $wl $obs $out $extra

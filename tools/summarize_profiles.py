@@ -31,6 +31,7 @@ def counters(raw, sub):
 
 def main():
     tag, wl, obs, raw = sys.argv[1:5]
+    extra = ' '.join(sys.argv[5:])                    # extra bench arguments the passes ran with, e.g. --no-export
     from gym_d2d_amd.build import source_digest
     stats = glob.glob(f'{raw}/kt/**/*kernel_stats.csv', recursive=True)
     if stats:
@@ -68,7 +69,7 @@ def main():
             if sq.get('SQ_WAVE_CYCLES'):
                 d['wait_any_fraction_of_wave_cycles'] = round(sq.get('SQ_WAIT_ANY', 0.0) / sq['SQ_WAVE_CYCLES'], 3)
     rec = {'command': 'tools/profile_bench.sh: rocprofv3 --pmc <one counter set per pass> --output-format csv -- python3 bench.py '
-                      f'--workload {wl} --obs {obs} --no-cpu-baseline --no-single-env-latency --steps 5 --warmup 1',
+                      f'--workload {wl} --obs {obs} --no-cpu-baseline --no-single-env-latency --no-extras {extra} --steps 5 --warmup 1'.replace('  ', ' '),
            'workload_key': f'{wl}/{obs}', 'source_digest': source_digest(), 'kernels': kernels}
     out = ROOT / 'profiles' / f'{tag}_pmc_{wl}_{obs}.json'
     out.write_text(json.dumps(rec, indent=1))
