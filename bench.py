@@ -6,21 +6,28 @@
 A "step" is one pass of the fused path over the whole batch: action decode -> SINR / SNR / rate / capacity -> reward
 -> observation table -> LinearObs expansion (reference semantics: obs materialised as [B, N, 6N] in HBM), with fresh
 i.i.d. actions every step (pre-generated in HBM; positions fixed for the run - the reference's step never moves
-devices, simulator.py:61-75).  Metric: agent-steps/s = B * N * steps / wall seconds (whole job, all GPUs).
+devices, simulator.py:61-75), driven through the PUBLIC batched API: VecD2DEnv.step(actions) -> (obs, rewards, dones, info).
+Metric: agent-steps/s = B * N * steps / wall seconds (whole job, all GPUs).
 
 N > 1: one process per GPU (torch.distributed / RCCL), env axis sharded 4096 per GPU (weak scaling), one all-gather
-per step of rewards + the per-step columns of the compact obs table, overlapped on a side stream.  `--gpus N` works
-both ways: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK is already set: this
-process IS a rank) and as a plain `python bench.py --gpus N` - then this process is only a launcher: it starts the N
-rank processes BEFORE anything touches HIP (it never imports torch, never re-execs), waits, and exits non-zero if any
-rank failed.
+per step of rewards + the per-step columns of the compact obs table, overlapped on a side stream (--gather rewards and
+--signal-every K select the lighter plans).  `--gpus N` works both ways: under `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N` (RANK is already set: this process IS a rank) and as a plain `python bench.py
+--gpus N` - then this process is only a launcher: it starts the N rank processes BEFORE anything touches HIP (it never
+imports torch, never re-execs), waits, and exits non-zero if any rank failed.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the library's stream),
-`cpu_baseline` (the NumPy fp64 oracle timed on this box's host cores on a bounded sample; rank 0, N = 1 only; one
-thread, with the all-core figure beside it) and, for N > 1, `rccl_ranks` + all-reduce / all-gather checksums.  At N = 1
-the line also carries, beside `value` and never as it: `core_mode` (the same envs stepped with the compact-table obs:
-throughput + the step kernel's roofline block) and `single_env_step_ms` (the drop-in single-env
-D2DEnv.step, host dicts in / out, at the reference's default shape and at the workload's).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the library's stream) and
+`cpu_baseline` (the oracle's plain-C restatement timed on this box's host cores on a bounded sample; rank 0, N = 1 only;
+one thread, with the all-core figure and the NumPy oracle's beside it).  Beside `value` and never as it:
+  N = 1  `core_mode` (the same envs stepped with the compact-table obs: throughput + the step kernel's roofline block,
+         SURVEY.md 8(d); without and with the optional decoded (rb, pwr) planes), `other_workloads` (BASELINE configs 2 and 4
+         and an episode loop with the device-side reset, each with its own roofline block), `vec_env_step_ms` (the public
+         VecD2DEnv.step against the bare C-ABI handle loop), `box_write_ceiling` / `roofline.box_ceiling_GBs` (the best of a
+         family of pure fill kernels on this box), `single_env_step_ms` (the drop-in single-env D2DEnv.step, host dicts in /
+         out); `--no-extras` keeps the headline only;
+  N > 1  `rccl_ranks` + all-reduce / all-gather checksums, `value_per_gpu`, `per_rank` (every rank's own ms per step and kernel
+         times), `gather` (bytes per GPU and step, side-stream ms per step, the same steps without the gather, the exposed
+         difference), and `core_mode` with the rewards-only gather plan.
 """
 import argparse
 import json
