@@ -26,7 +26,8 @@ def main():
     probe = [h.probe_write_bandwidth(8 << 30, 5) for _ in range(3)]
     print('fill probe GB/s (8 GiB, nontemporal 16B/lane):', [round(x) for x in probe])
     rows_opts = [0, 1, 2, 3, 4, 6] if n == 512 else [0, 1, 2, 5, 10, 25, 50]
-    variants = [(rows, 1, blk, xcd) for rows in rows_opts for blk in (384, 512, 640, 768, 896, 1024) for xcd in (1, 0) if rows <= n]
+    variants = [(rows, nt, blk, xcd) for rows in rows_opts for blk in (384, 512, 640, 768, 896, 1024) for xcd in (1, 0) for nt in (1, 0)
+                if rows <= n and (xcd == 1 or nt == 1)]
     times = {v: [] for v in variants}
     bytes_per = b * n * (24.0 * n + 24.0)
     for rnd in range(5):
