@@ -287,6 +287,8 @@ def parse_args(argv=None):
     ap.add_argument('--gather', default='table', choices=['table', 'rewards'],
                     help="N > 1: what the per-step all-gather carries (StepGatherer mode): rewards + the (sinr, snr) columns of the "
                          "obs table, or rewards only")
+    ap.add_argument('--gather-backend', default='torch', choices=['torch', 'native'],
+                    help="N > 1: torch.distributed collectives (nccl = RCCL) or the library's own RCCL entry (d2d_comm_init / d2d_allgather)")
     ap.add_argument('--signal-every', type=int, default=1, help='N > 1, --gather table: the (sinr, snr) columns travel on every K-th step')
     ap.add_argument('--with-reset', action='store_true', help='redraw all device positions every 10 steps (device-side reset)')
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
@@ -576,7 +578,9 @@ def worker(args):
 
     def make_gatherer(mode, signal_every=1):
         from gym_d2d_amd.distributed import StepGatherer
-        return StepGatherer(b, n, dev, mode=mode, signal_every=signal_every, timing=not stub)
+        native = args.gather_backend == 'native' and not stub and not args.share_gpu
+        return StepGatherer(b, n, dev, mode=mode, signal_every=signal_every, timing=not stub,
+                            backend='native' if native else 'torch', handle=sess.h if native else None)
 
     gatherer = make_gatherer(args.gather, args.signal_every) if use_dist and not args.no_gather else None
     t = sess.timed(fence, gatherer, args.with_reset)
@@ -628,7 +632,7 @@ def worker(args):
             tn = torch.tensor([t_nogather['dt']], device=dev, dtype=torch.float64)
             dist.all_reduce(tn, op=dist.ReduceOp.MAX)
             dist_info['gather'] = {
-                'mode': args.gather, 'signal_every': args.signal_every,
+                'mode': args.gather, 'signal_every': args.signal_every, 'backend': gatherer.backend,
                 'bytes_per_gpu_per_step': gatherer.bytes_per_signal_launch if args.signal_every == 1 else
                 gatherer.bytes_per_launch + (gatherer.bytes_per_signal_launch - gatherer.bytes_per_launch) / args.signal_every,
                 'gather_ms_per_step': gather_ms,                                   # side-stream events, rank 0

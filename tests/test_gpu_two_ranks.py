@@ -123,3 +123,20 @@ def test_bench_two_ranks_on_one_gpu_agree_with_one_rank_of_twice_the_envs():
     assert one.returncode == 0, one.stderr[-3000:]
     rank0 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][0])
     assert abs(two['allgather_reward_checksum'] - 2 * rank0['allgather_reward_checksum']) > 1e-3
+
+
+def test_bench_native_gather_backend_with_one_rank():
+    """`bench.py --gather-backend native`: the per-step gather through the C ABI's own RCCL entry (d2d_comm_init /
+    d2d_allgather on the side stream) instead of torch.distributed - with one rank, which is all RCCL admits on a one-GPU box;
+    the headline gather (table plan) and core_mode's rewards-only plan each build their own communicator."""
+    import json
+    import subprocess
+    cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '1', '--force-dist', '--gather-backend', 'native', '--envs', '64',
+           '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-single-env-latency']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert line['rccl_ranks'] == 1 and line['checksums_agree'] is True and line['gather']['backend'] == 'native'
+    assert line['allgather_envs'] == 64 and line['gather']['gather_ms_per_step'] > 0
+    assert line['core_mode']['gather']['mode'] == 'rewards' and line['core_mode']['gather']['gather_ms_per_step'] > 0
