@@ -46,13 +46,16 @@ def _check_step(sim, native, case, s, tag):
     assert (obs == orc.expand_obs(table[None])[0]).all(), tag
 
 
+@pytest.mark.parametrize('walk', [-1, 2], ids=['auto', 'member_lists'])
 @pytest.mark.parametrize('name', [n for n in case_names() if 'shadowing' not in n])
-def test_golden_cases_low_level(native, name):
-    """Every golden case through Simulator.step_arrays (C ABI), all three reward functions."""
+def test_golden_cases_low_level(native, name, walk):
+    """Every golden case through Simulator.step_arrays (C ABI), all three reward functions; with the default interferer
+    search and with the per-RB member lists (the reference's 4-RB / 40-link case puts ten links on every RB: list overflow)."""
     case = load_case(name)
     sim = _sim_for(case)
     h = sim.handle
     h.set_obs_mode(native.OBS_LINEAR)
+    h.set_tuning(native.TUNE_STEP_WALK, walk)
     for k, s in enumerate(case.steps):
         keys = [tuple(key.split(':')) for key in s.keys]
         sim.set_links(keys)
