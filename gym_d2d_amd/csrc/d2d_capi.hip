@@ -1026,8 +1026,13 @@ int d2d_step_host(d2d_handle* h, const int32_t* rb_host, const int32_t* pwr_host
     }
     std::memcpy(h->host_in_pinned, rb_host, bn * 4);
     std::memcpy(h->host_in_pinned + bn, pwr_host, bn * 4);
-    HIP_TRY(hipMemcpyAsync(h->host_in_dev, h->host_in_pinned, 2 * bn * 4, hipMemcpyHostToDevice, h->stream));
-    char* base = static_cast<char*>(h->host_out_dev);
+    // Small results (the reference's default env: 75 KB): the kernels read (rb, pwr) from and write every result to the PINNED
+    // HOST blocks directly over PCIe - no copy commands, one launch (or two) and one synchronisation.  Larger ones keep the
+    // staged device block and the two DMA copies (a 6 MB obs block written store by store over PCIe would crawl).
+    static const size_t zero_copy_limit = [] { const char* e = std::getenv("D2D_STEP_HOST_ZERO_COPY_BYTES"); return e ? (size_t)std::atoll(e) : (size_t)(256 * 1024); }();
+    const bool zero_copy = L.total_bytes <= zero_copy_limit;
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->host_in_dev, h->host_in_pinned, 2 * bn * 4, hipMemcpyHostToDevice, h->stream));
+    char* base = static_cast<char*>(zero_copy ? h->host_out_pinned : h->host_out_dev);
     OutPtrs o;
     o.sinr = reinterpret_cast<float*>(base + L.sinr_db); o.snr = reinterpret_cast<float*>(base + L.snr_db);
     o.rate = reinterpret_cast<float*>(base + L.rate_bps); o.cap = reinterpret_cast<float*>(base + L.capacity);
@@ -1036,9 +1041,10 @@ int d2d_step_host(d2d_handle* h, const int32_t* rb_host, const int32_t* pwr_host
     o.table = reinterpret_cast<float*>(base + L.obs_table);
     o.env_flags = reinterpret_cast<int*>(base + L.env_flags);
     o.obs = reinterpret_cast<float*>(base + L.obs);
-    int rc = run_step(h, 1, h->host_in_dev, h->host_in_dev + bn, &o);
+    const int32_t* in = zero_copy ? h->host_in_pinned : h->host_in_dev;
+    int rc = run_step(h, 1, in, in + bn, &o);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h->host_out_pinned, h->host_out_dev, L.total_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(h->host_out_pinned, h->host_out_dev, L.total_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *out_host = h->host_out_pinned;
     *layout = L;

@@ -249,7 +249,8 @@ int d2d_expand_table(d2d_handle* h, const float* table_dev, int32_t n_envs, int3
  * memory in, every result of the step back in ONE pinned host block - one H2D copy, the kernels, one
  * D2H copy, one synchronisation.  *out_host points at library-owned pinned memory laid out as
  * d2d_host_layout says (offsets in bytes), valid until the next call on this handle.  The D2D_BUF_*
- * output buffers are NOT updated by this entry.  As with d2d_step_rb_pwr, a link that carries a fixed
+ * output buffers are NOT updated by this entry.  (Blocks of up to 256 KB are written by the kernels straight
+ * into the pinned host memory - no copy commands; larger ones are staged in device memory.)  As with d2d_step_rb_pwr, a link that carries a fixed
  * action (d2d_set_fixed_actions) keeps it: the caller's (rb, pwr) entries for that link are ignored and
  * the returned rb / pwr regions hold the values the kernel used.                                      */
 typedef struct d2d_host_layout {
