@@ -84,9 +84,15 @@ __device__ __forceinline__ unsigned long long to_fixed_32_32(float v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// (d^2)^(-e/2) for arbitrary exponent e, to ~3e-7 relative.  log2 of the mantissa and the integer exponent
+// (d^2)^(-e/2) for arbitrary exponent e, to 2.5e-7 relative (mean 3e-8).  log2 of the mantissa and the integer exponent
 // are handled separately so the error does not scale with |log2(d^2)| (a plain exp2(h*log2(x)) loses ~2e-6).
 __device__ __forceinline__ float pow_neg_half(float d2, float e) {
+    // Contraction OFF in here: hipcc's default -ffp-contract=fast fuses `h * fe - ip` below into one FMA, which no longer rounds
+    // p - and the exact residual `perr` of the ROUNDED product then lands on top of an unrounded one.  Measured on the hardware
+    // over d in [1 m, 1 km], e in [2.05, 4.6] (tools/probes/pow_accuracy.hip): max relative error 1.56e-6 (mean 2.3e-7) as the
+    // compiler fused it, 2.5e-7 (mean 3.2e-8) as written - the difference between 1.02e-5 and < 5e-6 on the worst COST-Hata link
+    // of a 2000-scenario random search (round 3).
+#pragma clang fp contract(off)
     const float m = __builtin_amdgcn_frexp_mantf(d2);       // [0.5, 1)
     const float fe = (float)__builtin_amdgcn_frexp_expf(d2);
     const float l = __builtin_amdgcn_logf(m);               // v_log_f32 = log2, in [-1, 0)

@@ -3,7 +3,7 @@ downlinks, sidelinks in any order), every built-in path-loss model and reward fu
 oracle on the same float32 inputs.  `pytest -m gpu`."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings
+from hypothesis import HealthCheck, example, given, settings
 from hypothesis import strategies as st
 
 from golden_util import rel_err
@@ -68,6 +68,10 @@ def _path_loss(model, ple):
     return Hata, orc.PathLossSpec('cost_hata', 2.1, area='urban' if model == 'hata_urban' else 'suburban')
 
 
+# found by a 2000-scenario random search in round 3: COST-Hata, |SINR| = 0.86 dB on the worst link, 1.02e-5 while hipcc's
+# default fp contraction fused away the exact residual inside pow_neg_half (csrc/d2d_step.hip); 2.8e-6 as written
+@example(dict(walk=-1, big=True, rbs=14, cues=38, dues=67, envs=2, seed=37263, model='hata_urban', ple=2.0, reward=1,
+              reward_param=0.0, n_over=2, use_downlinks=False, explicit=False))
 @settings(max_examples=240, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(scenarios())
 def test_random_scenarios_match_oracle(tmp_path_factory, sc):
