@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Fuzz: random shapes x random launch / search / option settings of the step kernel must reproduce the all-pairs sweep of the
+generic kernel BIT FOR BIT on every output (the committed tests pin chosen shapes; this walks the space for a few minutes).
+
+    python tools/fuzz_variants.py [seconds]
+"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / 'tests')]
+from gym_d2d_amd import _native as nat
+from gym_d2d_amd.simulator import Simulator
+from sim_util import random_layout
+
+OUTS = ('BUF_SINR_DB', 'BUF_SNR_DB', 'BUF_RATE_BPS', 'BUF_CAPACITY', 'BUF_REWARD', 'BUF_OBS_TABLE', 'BUF_RB', 'BUF_PWR', 'BUF_ENV_FLAGS')
+
+
+def snap(sim, linear):
+    out = {n: sim.fetch(getattr(nat, n)).copy() for n in OUTS}
+    if linear:
+        out['BUF_OBS'] = sim.fetch(nat.BUF_OBS).copy()
+    return out
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(time.time()))
+    t0, cases, runs = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        kind = rng.integers(0, 4)
+        if kind == 0:      # one link per thread, one env per workgroup (the rollout specialisation when N % 64 == 0)
+            n = int(rng.choice([64, 128, 192, 256, 512])); cues = n // 2; dues = n - cues
+        elif kind == 1:    # small envs sharing a workgroup
+            cues, dues = int(rng.integers(0, 40)), int(rng.integers(1, 40))
+        elif kind == 2:    # odd sizes
+            cues, dues = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        else:              # beyond the masks
+            cues, dues = int(rng.integers(500, 1024)), int(rng.integers(525, 1024))
+        rbs = int(rng.choice([1, 2, 5, 16, 64, 300, max(1, (cues + dues) // 2)]))
+        b = int(rng.integers(1, 20)) if cues + dues > 600 else int(rng.integers(1, 70))
+        reward = int(rng.integers(1, 4))
+        linear = cues + dues <= 128 and rng.random() < 0.5
+        model = rng.choice(['log2', 'ple'])
+        cfg = dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b)
+        if model == 'ple':
+            from gym_d2d_amd.path_loss import LogDistancePathLoss
+
+            class Ple(LogDistancePathLoss):
+                def __init__(self, f):
+                    super().__init__(f, ple=3.3)
+            cfg['path_loss_model'] = Ple
+        sim = Simulator(cfg)
+        pos = random_layout(rng, b, cues, dues)
+        sim.set_positions(pos)
+        sim.set_links(sim.default_link_keys())
+        p = sim.config.num_pwr_actions
+        raw = np.concatenate([rng.integers(0, rbs * p['cue'], (b, cues)), rng.integers(0, rbs * p['due'], (b, dues))], 1).astype(np.int32)
+        if rng.random() < 0.3 and cues + dues > 3:           # a skewed policy: most links on two RBs
+            hot = rng.integers(0, cues + dues, (cues + dues) // 2)
+            lv = np.array([p['cue']] * cues + [p['due']] * dues)
+            raw[:, hot] = (rng.integers(0, min(2, rbs), (b, hot.size)) * lv[hot] + 3).astype(np.int32)
+        if rng.random() < 0.2:
+            raw[rng.integers(0, b), rng.integers(0, cues + dues)] = -7   # rb = -1: out of range
+        h = sim.handle
+        h.set_obs_mode(nat.OBS_LINEAR if linear else nat.OBS_TABLE)
+        h.set_reward(reward, {1: float(rng.choice([0.0, 0.4])), 2: -70.0, 3: 0.0}[reward])
+        h.set_bucketing(False)
+        sim.step_arrays(raw)
+        ref = snap(sim, linear)
+        h.set_bucketing(True)
+        for _ in range(5):
+            tune = {nat.TUNE_STEP_WALK: int(rng.choice([-1, 0, 1, 2])), nat.TUNE_STEP_SCALAR_RECORDS: int(rng.choice([-1, 0, 1])),
+                    nat.TUNE_STEP_NT_RESULTS: int(rng.choice([0, 1])), nat.TUNE_STEP_OBS_ROTATE: int(rng.choice([-1, 0, 7])),
+                    nat.TUNE_STEP_LPT: int(rng.choice([-1, 1, 2])) if cues + dues <= 1024 else -1,
+                    nat.TUNE_STEP_ENVS_PER_WG: int(rng.choice([0, 1, 2, 4])) if cues + dues <= 128 else 0,
+                    nat.TUNE_STEP_FUSE_OBS: int(rng.choice([-1, 0, 1])) if linear else -1}
+            if tune[nat.TUNE_STEP_LPT] == 1 and cues + dues > 1024:
+                tune[nat.TUNE_STEP_LPT] = -1
+            for k, v in tune.items():
+                h.set_tuning(k, v)
+            export = bool(rng.random() < 0.7)
+            h.set_export_actions(export)
+            if not export:
+                h.upload(nat.BUF_RB, ref['BUF_RB']); h.upload(nat.BUF_PWR, ref['BUF_PWR'])
+            sim.step_arrays(raw)
+            got = snap(sim, linear)
+            runs += 1
+            for name, r in ref.items():
+                if name == 'BUF_REWARD' and reward == 1 and tune[nat.TUNE_STEP_LPT] == 2 and cues + dues <= 1024:
+                    # two links per thread add the capacities in another order than one link per thread: last-bit differences
+                    ok = np.allclose(got[name], r, rtol=2e-6, atol=0.0, equal_nan=True)
+                elif name == 'BUF_ENV_FLAGS':
+                    ok = np.array_equal(got[name], r)
+                else:
+                    ok = np.array_equal(got[name], r, equal_nan=True)
+                if not ok:
+                    print('MISMATCH', name, dict(b=b, rbs=rbs, cues=cues, dues=dues, reward=reward, linear=linear, model=str(model), export=export),
+                          {int(k): v for k, v in tune.items()}, flush=True)
+                    sys.exit(1)
+        h.set_export_actions(True)
+        h.close()
+        cases += 1
+    print(f'fuzz ok: {cases} random cases, {runs} variant runs, all outputs bit-identical to the all-pairs sweep', flush=True)
+
+
+if __name__ == '__main__':
+    main()
