@@ -70,6 +70,7 @@ struct d2d_handle {
     Buffer buf[D2D_BUF_COUNT];
     // device-side tables
     float4* rec = nullptr;          // per-link records: 3 rows of Nmax x 16 B (d2d_internal.h), see refresh_tables
+    float2* rec_h = nullptr;        // per-link (head, tail) of -exponent / 2, see refresh_tables
     int* act_cols = nullptr;        // [Nmax] action column per link (arbitrary fixed sets)
     unsigned* side_words = nullptr; // [ceil(Nmax / 32)] sidelink membership bits, rebuilt with the records
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
@@ -202,6 +203,19 @@ int refresh_tables(d2d_handle* h) {
         rc[4 * i + 1] = cols[5 * D + t];    // bw_mhz
         rc[4 * i + 2] = cols[6 * D + t];    // exponent
     }
+    // -exponent / 2 of every link's transmitter as head + tail: the head keeps the 12 leading bits (its product with a binary
+    // exponent is exact in the kernel), the tail the rest of the DOUBLE - the pair carries ~36 bits, so that the exponent's own
+    // rounding (6e-8 as a float, amplified by ln(d^2) e / 2 in (d^2)^(-e/2): 1.2e-6 at 300 m, e = 3.5) leaves the result
+    std::vector<float> rech((size_t)2 * S, 0.0f);
+    for (int i = 0; i < N; ++i) {
+        const double hd = h->mode == d2d::PL_TABLE ? -1.0 : -0.5 * h->expo[h->host_tx[i]];
+        float head = (float)hd;
+        uint32_t hb;
+        std::memcpy(&hb, &head, 4); hb &= 0xFFFFF000u; std::memcpy(&head, &hb, 4);
+        rech[2 * i] = head;
+        rech[2 * i + 1] = (float)(hd - (double)head);
+    }
+    HIP_TRY(hipMemcpyAsync(h->rec_h, rech.data(), rech.size() * 4, hipMemcpyHostToDevice, h->stream));
     std::vector<int32_t> cols_host((size_t)S, 0);
     for (int i = 0; i < N; ++i) {
         uint32_t packed;
@@ -233,7 +247,7 @@ int refresh_tables(d2d_handle* h) {
                   std::memcmp(&rc[4 * i], &rc[4 * g], 12) == 0;
         uint32_t pi, pg;
         std::memcpy(&pi, &rc[4 * i + 3], 4); std::memcpy(&pg, &rc[4 * g + 3], 4);
-        uniform = uniform && (pi & 0xFFFFu) == (pg & 0xFFFFu);
+        uniform = uniform && (pi & 0xFFFFu) == (pg & 0xFFFFu) && rech[2 * i] == rech[2 * g] && rech[2 * i + 1] == rech[2 * g + 1];
     }
     h->rec_uniform = uniform;
     h->tables_dirty = false;
@@ -474,6 +488,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.rec_a = reinterpret_cast<const int4*>(h->rec);
     s.rec_b = h->rec + S;
     s.rec_c = h->rec + 2 * (size_t)S;
+    s.rec_h = h->rec_h;
     s.lpos = h->lpos;
     s.act_cols = h->act_cols;
     s.side_words = h->side_words;
@@ -596,6 +611,7 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     CREATE_TRY(hipMalloc(&h->rec, (size_t)3 * h->Nmax * 16));
+    CREATE_TRY(hipMalloc(&h->rec_h, (size_t)h->Nmax * 8));
     CREATE_TRY(hipMalloc(&h->lpos, (size_t)h->B * h->Nmax * 16));
     CREATE_TRY(hipMalloc(&h->act_cols, (size_t)h->Nmax * 4));
     CREATE_TRY(hipMalloc(&h->side_words, ((size_t)(h->Nmax + 31) / 32 + 1) * 4));
@@ -615,6 +631,7 @@ int d2d_destroy(d2d_handle* h) {
     for (auto& bf : h->buf)
         if (bf.ptr && bf.owned) hipFree(bf.ptr);
     if (h->rec) hipFree(h->rec);
+    if (h->rec_h) hipFree(h->rec_h);
     if (h->lpos) hipFree(h->lpos);
     if (h->dbg) hipFree(h->dbg);
     if (h->act_cols) hipFree(h->act_cols);

@@ -19,7 +19,8 @@ enum PlMode : int {
 //              z, w: fixed ? (rb, tx power dBm) : (division magic ceil(2^32 / P), largest action it is exact for; 0, 0 = divide)
 //   b (float4) x: tx_lin = 10^((eirp_off - a_tx)/10)   y: rx_pl = 10^(-a_rx/10)   z: rx_lin = 10^(rx_off/10)
 //              w: noise_mw = 10^(thermal_noise_dBm/10)
-//   c (float4) x: rx_sensitivity_dBm   y: 1e-6 * RB bandwidth (Hz) of the tx   z: path-loss exponent of the tx
+//   c (float4) x: rx_sensitivity_dBm   y: 1e-6 * RB bandwidth (Hz) of the tx   z: path-loss exponent of the tx (informative: the
+//              kernels read the head / tail pair of -exponent / 2 from rec_h, which carries more than float precision)
 //              w: (bits) P = power levels of this link's type (d2d_env.py:31-35) | action column << 16
 #define D2D_REC_TXDEV_MASK 0x00FFFFFF
 #define D2D_REC_TYPE_SHIFT 24
@@ -68,6 +69,7 @@ struct StepArgs {
     const int4* rec_a;       // [N]
     const float4* rec_b;     // [N]
     const float4* rec_c;     // [N]
+    const float2* rec_h;     // [N] head / tail of -exponent / 2 of the link's transmitter (power-law / shadowing kernels)
     const int* act_cols;     // [N] action column of every link (col_mode 1 only; 0 for fixed links)
     const unsigned* side_words;  // [ceil(N / 32)] bit i set <=> link i is a sidelink (host-built with the records)
     const float4* lpos;      // [B, N] (tx_x, tx_y, rx_x, rx_y) of every link, rebuilt when positions / links change

@@ -84,23 +84,22 @@ __device__ __forceinline__ unsigned long long to_fixed_32_32(float v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// (d^2)^(-e/2) for arbitrary exponent e, to 2.5e-7 relative (mean 3e-8).  log2 of the mantissa and the integer exponent
-// are handled separately so the error does not scale with |log2(d^2)| (a plain exp2(h*log2(x)) loses ~2e-6).
-__device__ __forceinline__ float pow_neg_half(float d2, float e) {
-    // Contraction OFF in here: hipcc's default -ffp-contract=fast fuses `h * fe - ip` below into one FMA, which no longer rounds
-    // p - and the exact residual `perr` of the ROUNDED product then lands on top of an unrounded one.  Measured on the hardware
-    // over d in [1 m, 1 km], e in [2.05, 4.6] (tools/probes/pow_accuracy.hip): max relative error 1.56e-6 (mean 2.3e-7) as the
-    // compiler fused it, 2.5e-7 (mean 3.2e-8) as written - the difference between 1.02e-5 and < 5e-6 on the worst COST-Hata link
-    // of a 2000-scenario random search (round 3).
+// (d^2)^h for h = -e/2 given as a head + tail pair (h.x: the 12 leading bits of h, so that h.x * exponent is exact; h.y = h - h.x,
+// both built by the host in double precision, d2d_capi.hip::refresh_tables), to ~2.5e-7 relative.  log2 of the mantissa and the
+// integer exponent are handled separately so the error does not scale with |log2(d^2)| (a plain exp2(h*log2(x)) loses ~2e-6), and
+// the EXPONENT ITSELF carries more than float precision: a float32 e is off by up to 6e-8 relative, which (d^2)^(-e/2) amplifies by
+// ln(d^2) * e/2 - 1.2e-6 at 300 m with COST-Hata's e = 3.5, the largest single term of the power-law modes' error until round 3.
+__device__ __forceinline__ float pow_neg_half(float d2, float2 h) {
+    // Contraction OFF in here: hipcc's default -ffp-contract=fast fuses products into the additions below, and the head / tail
+    // arithmetic then adds exact residuals to unrounded terms.  Measured on the hardware (tools/probes/pow_accuracy.hip, the r2 form
+    // of this function): max relative error 1.56e-6 as the compiler fused it, 2.5e-7 as written.
 #pragma clang fp contract(off)
     const float m = __builtin_amdgcn_frexp_mantf(d2);       // [0.5, 1)
     const float fe = (float)__builtin_amdgcn_frexp_expf(d2);
     const float l = __builtin_amdgcn_logf(m);               // v_log_f32 = log2, in [-1, 0)
-    const float h = -0.5f * e;
-    const float p = h * fe;
-    const float perr = fmaf(h, fe, -p);                     // exact residual of the product
+    const float p = h.x * fe;                               // exact: 12 bits x at most 8
     const float ip = rintf(p);
-    const float fr = (p - ip) + fmaf(h, l, perr);
+    const float fr = (p - ip) + fmaf(h.x, l, h.y * (l + fe));
     return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(fr), (int)ip);
 }
 
@@ -115,9 +114,9 @@ __device__ __forceinline__ float pow10_tenth(int p) {
 }
 
 template <int MODE>
-__device__ __forceinline__ float pair_gain(float d2, float e) {
+__device__ __forceinline__ float pair_gain(float d2, float2 h) {
     if (MODE == PL_INV_SQUARE) return __builtin_amdgcn_rcpf(d2);
-    return pow_neg_half(d2, e);
+    return pow_neg_half(d2, h);
 }
 
 // Philox4x32-10 (same generator as csrc/d2d_reset.hip), used for the per-call Gaussian of ShadowingPathLoss.
@@ -154,7 +153,7 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
 //        aux[N] i32 (tx_dev | type << 24)                       always (all-pairs fallback, table route)
 //        rx[N] float2                                           strided links only (LPT == 0)
 //        sinr[N], sh[N] f32                                     Shannon / CueSinrShannon rewards
-//        expo[N] f32                                            power-law / shadowing path loss
+//        expo[N] float2 (head, tail of -exponent / 2)          power-law / shadowing path loss
 //        tflat[6N] f32                                          fused obs expansion
 //   off_mask: mask[W][R] u32 per-RB membership, word-major (lanes with different RBs hit different banks),
 //             side[W] u32 sidelink membership, summ[R] u32 (bit w set <=> mask[w][rb] != 0)
@@ -168,7 +167,8 @@ void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int re
     out->aux = off; off += (unsigned)N * 4u;
     out->rx = off; if (lpt == 0) off += (unsigned)N * 8u;
     out->sinr = off; out->sh = off + (unsigned)N * 4u; if (reward_fn >= 2) off += (unsigned)N * 8u;
-    out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW) off += NL * 4u;
+    off = (off + 7u) & ~7u;
+    out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW) off += NL * 8u;      // (head, tail) of -exponent / 2 per link
     off = (off + 7u) & ~7u;
     out->tflat = off; if (fuse_obs) off += (unsigned)N * 24u;
     off = (off + 15u) & ~15u;                            // the mask region is cleared with 16-byte stores
@@ -189,7 +189,7 @@ size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lp
 }
 
 struct Smem {
-    float* red; int* flags; float4* link; float2* rx; float* sinr; float* sh; float* expo; int* aux; float* tflat;
+    float* red; int* flags; float4* link; float2* rx; float* sinr; float* sh; float2* expo; int* aux; float* tflat;
     unsigned* mask; unsigned* side; unsigned* summ;
     uint4* slots; unsigned* cnt;
 };
@@ -203,7 +203,7 @@ __device__ __forceinline__ Smem carve(unsigned char* base, const StepLds& l, uns
     s.rx = reinterpret_cast<float2*>(base + l.rx);
     s.sinr = reinterpret_cast<float*>(base + l.sinr);
     s.sh = reinterpret_cast<float*>(base + l.sh);
-    s.expo = reinterpret_cast<float*>(base + l.expo);
+    s.expo = reinterpret_cast<float2*>(base + l.expo);
     s.tflat = reinterpret_cast<float*>(base + l.tflat);
     s.mask = reinterpret_cast<unsigned*>(base + l.mask);
     s.side = s.mask + R * W;
@@ -235,6 +235,7 @@ struct LinkRaw {
     int4 ra;             // rec_a
     float4 rb_;          // rec_b: tx_lin, rx_pl, rx_lin, noise_mw
     float4 rc;           // rec_c: sens_db, bw_mhz, exponent, (P | column << 16)
+    float2 hh;           // rec_h: head / tail of -exponent / 2 (power-law and shadowing modes only)
     float4 pos;          // tx_x, tx_y, rx_x, rx_y
     int act0, act1;      // raw action, or explicit (rb, pwr)
 };
@@ -242,15 +243,21 @@ struct LinkRaw {
 // load through the constant address space: with a wave-uniform address the compiler selects s_load_dwordx4 (the data is
 // written by the host between launches only)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ i32x4 scalar_load16(const void* p) {
     typedef const __attribute__((address_space(4))) i32x4* cptr;
     return *reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(p));
 }
+__device__ __forceinline__ i32x2 scalar_load8(const void* p) {
+    typedef const __attribute__((address_space(4))) i32x2* cptr;
+    return *reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(p));
+}
 
 __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, unsigned act_row, int i, int action_mode, int col_mode,
-                                             bool no_fixed = false, bool srec = false) {
+                                             bool no_fixed = false, bool srec = false, bool need_h = false) {
     LinkRaw in;
     in.act0 = 0; in.act1 = 0;
+    in.hh = make_float2(-1.0f, 0.0f);
     // actions first, branch-free per lane (uniform branches only), so that no join forces a wait on the loads in flight
     if (action_mode == 0) {
         if (no_fixed) {
@@ -277,10 +284,12 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
         in.ra = make_int4(va.x, va.y, va.z, va.w);
         in.rb_ = make_float4(__int_as_float(vb.x), __int_as_float(vb.y), __int_as_float(vb.z), __int_as_float(vb.w));
         in.rc = make_float4(__int_as_float(vc.x), __int_as_float(vc.y), __int_as_float(vc.z), __int_as_float(vc.w));
+        if (need_h) { const i32x2 vh = scalar_load8(a.rec_h + iu); in.hh = make_float2(__int_as_float(vh.x), __int_as_float(vh.y)); }
     } else {
         in.ra = a.rec_a[i];
         in.rb_ = a.rec_b[i];
         in.rc = a.rec_c[i];
+        if (need_h) in.hh = a.rec_h[i];
     }
     in.pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
     return in;
@@ -416,6 +425,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr int KEEP = LPT > 0 ? LPT : 1;
     constexpr int UNROLL_LINKS = LPT > 0 ? LPT : 1;                // strided kernels: the per-link bodies are not unrolled
     constexpr bool LISTS = (OPT & OPT_LISTS) != 0, SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0;
+    constexpr bool POWLAW = MODE == PL_POWER || MODE == PL_SHADOW;   // per-link exponents (rec_h, LDS expo[])
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
     const int cfg_col_mode = HOT ? 0 : a.col_mode;
     const int cfg_reward_fn = HOT ? 1 : a.reward_fn;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) {
         const int i = lt + u * TPE;
-        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1, SREC);
+        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1, SREC, POWLAW);
     }
     // ---- pass 0: clear masks and flags
     const bool have_masks = HOT || W > 0;                          // mask region allocated
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             for (int k = lt; k < nl; k += TPE) { const unsigned f = k < R ? 0xFFFFFFFFu : 0u; s.slots[k] = make_uint4(f, f, f, f); }
             if (lt == TPE - 1) {
                 s.link[N] = make_float4(1.0e18f, 1.0e18f, 0.0f, __int_as_float(-1));
-                if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[N] = 2.0f;
+                if (POWLAW) s.expo[N] = make_float2(-1.0f, 0.0f);
             }
         } else if (want_masks) clear_masks<FULL>(s, R, W, lt, TPE);
         if (lt < 5) reinterpret_cast<uint4*>(s.red)[lt] = make_uint4(0u, 0u, 0u, 0u);   // red[16] + flags[4]: 80 bytes
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) { me0[u] = make_float4(0.f, 0.f, 0.f, 0.f); myslot[u] = 0u; }
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1);
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1, false, POWLAW);
         int rb, p;
         decode_link(a, in, act_row, rb, p, cfg_action_mode, HOT == 1);
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (!HOT) s.aux[i] = in.ra.x & 0x0FFFFFFF;                       // tx_dev | link_type << 24 (HOT: only the cold all-pairs
                                                                          // route wants the type, and reads it from the record)
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
-        if (MODE == PL_POWER || MODE == PL_SHADOW) s.expo[i] = in.rc.z;
+        if (POWLAW) s.expo[i] = in.hh;
         if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); ST(at(a.rb_out, oe), rb); ST(at(a.pwr_out, oe), p); }
         if (LISTS) {
             if (LIKELY((unsigned)rb < (unsigned)R)) {
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     int my_flags = 0;
     bool violated = false;
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1);   // strided links: records re-read (L2)
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1, false, POWLAW);   // strided links: records re-read (L2)
         const float4 me = IN_REGS(u) ? me0[KEPT(u)] : s.link[i];
         const float2 rx = make_float2(in.pos.z, in.pos.w);
         const int rb = __float_as_int(me.w);
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);                                                                 \
                 float g;                                                                                                \
                 if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];                                \
-                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); } \
+                else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); } \
                 if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, (int)(j), i, 0u);              \
                 acc = fmaf((o).z, g, acc);                               /* simulator.py:97-101, linear mW */            \
             }
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         const float d2 = fmaf(dx, dx, dy * dy);
                         float g;
                         if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
-                        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
+                        else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                         acc = fmaf(o.z, g, acc);                         // simulator.py:97-101, linear mW
                     }
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                             const float d2 = fmaf(dx, dx, dy * dy);
                             float g;
                             if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
-                            else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
+                            else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                             if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                             acc = fmaf(o.z, g, acc);                     // simulator.py:97-101, linear mW
                             asm volatile("" ::"v"(o.w));                 // .w kept live: the tuple comes by ds_read_b128 (4 LDS cycles), not b96 (8)
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
-                else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? s.expo[j] : 2.0f); if (MODE != PL_INV_SQUARE) dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
+                else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
                 if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                 acc = same ? fmaf(o.z, g, acc) : acc;
             }
@@ -758,7 +768,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)txd * D + rxd];
-        else { g = pair_gain<MODE>(d2, MODE != PL_INV_SQUARE ? in.rc.z : 2.0f); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
+        else { g = pair_gain<MODE>(d2, in.hh); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
         float sig = me.z * g * rx_pl * rx_lin;                           // mW at the receiver, with rx gains
         float sig_snr = sig;
         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
