@@ -66,6 +66,16 @@ def main():
         if rng.random() < 0.2:
             raw[rng.integers(0, b), rng.integers(0, cues + dues)] = -7   # rb = -1: out of range
         h = sim.handle
+        n_all = cues + dues
+        fixed_idx = np.zeros(0, dtype=np.int64)
+        if rng.random() < 0.35 and n_all > 2:              # traffic-model style links: (rb, pwr) held in the link records
+            if rng.random() < 0.5:
+                fixed_idx = np.arange(int(rng.integers(1, max(2, cues + 1))))                  # a prefix (the CUE block or part of it)
+            else:
+                fixed_idx = np.sort(rng.choice(n_all, size=int(rng.integers(1, n_all)), replace=False))   # an arbitrary set
+            h.set_fixed_actions(fixed_idx, rng.integers(0, rbs, fixed_idx.size), rng.integers(0, 40, fixed_idx.size))
+            keep = np.setdiff1d(np.arange(n_all), fixed_idx)
+            raw = np.ascontiguousarray(raw[:, keep])
         h.set_obs_mode(nat.OBS_LINEAR if linear else nat.OBS_TABLE)
         h.set_reward(reward, {1: float(rng.choice([0.0, 0.4])), 2: -70.0, 3: 0.0}[reward])
         h.set_bucketing(False)
@@ -104,6 +114,31 @@ def main():
         h.set_export_actions(True)
         h.close()
         cases += 1
+    # d2d_step_host on both sides of its zero-copy limit (256 KB of results: N = 100 links of one env with LinearObs is 245 KB,
+    # N = 104 is 264 KB): the packed host block must equal d2d_step_rb_pwr + per-buffer downloads either way
+    hosts = 0
+    for n in list(range(94, 112)) + [30, 300]:
+        for obs_mode in (nat.OBS_LINEAR, nat.OBS_TABLE):
+            cues, dues, rbs, b = n // 2, n - n // 2, 9, (1 if obs_mode == nat.OBS_LINEAR else int(rng.integers(1, 60)))
+            sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b))
+            sim.set_positions(random_layout(rng, b, cues, dues))
+            sim.set_links(sim.default_link_keys())
+            h = sim.handle
+            h.set_obs_mode(obs_mode)
+            rb = rng.integers(0, rbs, (b, n)).astype(np.int32); pw = rng.integers(0, 20, (b, n)).astype(np.int32)
+            sim.step_arrays(rb=rb, pwr=pw)
+            want = snap(sim, obs_mode == nat.OBS_LINEAR)
+            res = h.step_host(rb, pw)
+            for key, buf in (('sinr_db', 'BUF_SINR_DB'), ('snr_db', 'BUF_SNR_DB'), ('rate_bps', 'BUF_RATE_BPS'), ('capacity', 'BUF_CAPACITY'),
+                             ('reward', 'BUF_REWARD'), ('obs_table', 'BUF_OBS_TABLE'), ('env_flags', 'BUF_ENV_FLAGS')) + \
+                    ((('obs', 'BUF_OBS'),) if obs_mode == nat.OBS_LINEAR else ()):
+                if not np.array_equal(res[key], want[buf]):
+                    print('MISMATCH step_host', key, dict(n=n, b=b, obs_mode=obs_mode), flush=True)
+                    sys.exit(1)
+            assert (res['rb'] == rb).all() and (res['pwr'] == pw).all()
+            h.close()
+            hosts += 1
+    print(f'step_host ok: {hosts} sizes around the zero-copy limit')
     print(f'fuzz ok: {cases} random cases, {runs} variant runs, all outputs bit-identical to the all-pairs sweep', flush=True)
 
 
