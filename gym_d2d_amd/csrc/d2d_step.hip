@@ -597,7 +597,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const int txd = in.ra.x & D2D_REC_TXDEV_MASK, rxd = in.ra.y;
         const float rx_pl = in.rb_.y, rx_lin = in.rb_.z, noise = in.rb_.w;
         const float sens = in.rc.x, bw_mhz = in.rc.y;
-        float acc = 0.0f;
+        // the interference sum in DOUBLE: each term is one rounded float product, but the running sum no longer drifts with the
+        // number of same-RB links (float: 4.4e-6 of the bar's 1e-5 at 512 links on one RB, 8.5e-6 at 2048, tools/probes/crowded_rb_error.py)
+        double acc = 0.0;
         int dmin = 0x7F000000;                                           // bits of the smallest squared distance met (d2 >= 0:
                                                                          // integer order == float order); 0 <=> 'math domain error'
         const bool use_lists = LISTS && IN_REGS(u) && lists_on && (unsigned)rb < (unsigned)R;
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];                                \
                 else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); } \
                 if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, (int)(j), i, 0u);              \
-                acc = fmaf((o).z, g, acc);                               /* simulator.py:97-101, linear mW */            \
+                acc += (double)((o).z * g);                              /* simulator.py:97-101, linear mW */            \
             }
             if (MODE == PL_INV_SQUARE || MODE == PL_POWER) {
                 // Empty slots are clamped onto the stand-in tuple at link[N] (zero power, 1e18 m away): fmaf(0, g, acc) leaves acc
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
                         else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
-                        acc = fmaf(o.z, g, acc);                         // simulator.py:97-101, linear mW
+                        acc += (double)(o.z * g);                        // simulator.py:97-101, linear mW
                     }
                 }
             } else {
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                             if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd];
                             else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                             if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
-                            acc = fmaf(o.z, g, acc);                     // simulator.py:97-101, linear mW
+                            acc += (double)(o.z * g);                    // simulator.py:97-101, linear mW
                             asm volatile("" ::"v"(o.w));                 // .w kept live: the tuple comes by ds_read_b128 (4 LDS cycles), not b96 (8)
                         }
                         if (!more) break;
@@ -729,11 +731,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * D + rxd] : 0.0f;
                 else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
                 if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
-                acc = same ? fmaf(o.z, g, acc) : acc;
+                acc += same ? (double)(o.z * g) : 0.0;
             }
         }
 
-        if (D2D_STEP_ABLATE && a.dbg && acc == -1.0f) my_flags |= 1 << 30;   // (never true) pins the stamp behind the walk
+        if (D2D_STEP_ABLATE && a.dbg && acc == -1.0) my_flags |= 1 << 30;   // (never true) pins the stamp behind the walk
         STAMP(5);
         if (ABL(16384)) {                    // diagnostic: 64 extra VALU instructions per wave - is the kernel VALU bound?
             float x0 = me.x, x1 = me.y;
@@ -775,7 +777,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             sig_snr = sig * shadow_factor(a, genv, i, i, 1u);            // simulator.py:114: a second, independent draw
             sig *= shadow_factor(a, genv, i, i, 0u);                     // simulator.py:93
         }
-        const float ix = acc * rx_pl;                                    // interferers: no rx gains (simulator.py:100)
+        const float accf = (float)acc;
+        const float ix = accf * rx_pl;                                   // interferers: no rx gains (simulator.py:100)
         const float sinr_lin = precise_div(sig, ix + noise);
         // dB = 10 log10 x = 3.0103 log2 x, log2 on the transcendental unit (v_log_f32, 1 ulp): abs error < 6e-6 dB
         // at 80 dB and < 1e-6 dB near 0 dB, inside the 1e-5 * max(|ref|, 1) bar with an order of magnitude to spare
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             // non-finite SINR, so the common case is one compare and the cause is sorted out behind it
             if (UNLIKELY(!(fabsf(sinr_db) <= 3.0e38f))) {
                 my_flags |= FLAG_NON_FINITE;
-                if (d2 == 0.0f || !(acc <= 3.0e38f)) my_flags |= FLAG_ZERO_DISTANCE;
+                if (d2 == 0.0f || !(accf <= 3.0e38f)) my_flags |= FLAG_ZERO_DISTANCE;
             }
         } else {
             if (dmin == 0) my_flags |= FLAG_ZERO_DISTANCE;
