@@ -377,3 +377,21 @@ def test_write_ceiling_probe_family(native):
     with pytest.raises(native.NativeError):
         h.probe_write_bandwidth(1 << 20, 1)                 # below one group of regions
     h.close()
+
+
+@pytest.mark.parametrize('shape', [(3, 100000, 25, 25), (2, 5000, 300, 300), (1, 1, 0, 1), (1, 1, 1, 0), (2, 70000, 1000, 1000), (4, 1, 1, 1)])
+def test_edge_shapes_against_the_oracle(native, shape):
+    """More resource blocks than any per-RB structure fits in LDS (masks and lists both give way to the sweep), a single link, one
+    RB for everything, 2000 links on 70000 RBs: SINR, reward and flags against the oracle."""
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=sum(shape))
+    h = sim.handle
+    h.set_obs_mode(native.OBS_LINEAR if cues + dues <= 128 else native.OBS_TABLE)
+    sim.step_arrays(raw)
+    tx, rx, ty = default_links(cues, dues)
+    ref = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(*orc.device_configs(cues, dues)[1:]), orc.PathLossSpec(),
+                        with_obs=False, chunk=2)
+    assert rel_err(sim.fetch(native.BUF_SINR_DB), ref['sinr_db']) <= TOL
+    assert rel_err(sim.fetch(native.BUF_REWARD)[:, 0], ref['reward']) <= TOL
+    assert h.status_flags() == 0
+    h.close()
