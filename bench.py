@@ -289,6 +289,9 @@ def parse_args(argv=None):
                          "obs table, or rewards only")
     ap.add_argument('--gather-backend', default='torch', choices=['torch', 'native'],
                     help="N > 1: torch.distributed collectives (nccl = RCCL) or the library's own RCCL entry (d2d_comm_init / d2d_allgather)")
+    ap.add_argument('--reward-every', type=int, default=8,
+                    help='N > 1, rewards-only gather plan (--gather rewards, and core_mode): the rewards of K steps ride in a device-side '
+                         'ring and travel together (one gather launch costs more host time than a compact-obs step takes)')
     ap.add_argument('--signal-every', type=int, default=1, help='N > 1, --gather table: the (sinr, snr) columns travel on every K-th step')
     ap.add_argument('--with-reset', action='store_true', help='redraw all device positions every 10 steps (device-side reset)')
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
@@ -580,15 +583,18 @@ def worker(args):
         from gym_d2d_amd.distributed import StepGatherer
         native = args.gather_backend == 'native' and not stub and not args.share_gpu
         return StepGatherer(b, n, dev, mode=mode, signal_every=signal_every, timing=not stub,
+                            reward_every=args.reward_every if mode == 'rewards' else 1,
                             backend='native' if native else 'torch', handle=sess.h if native else None)
 
     gatherer = make_gatherer(args.gather, args.signal_every) if use_dist and not args.no_gather else None
+    total_steps = args.steps + args.warmup                    # launches the gatherer sees in the timed run (warm-up included)
     t = sess.timed(fence, gatherer, args.with_reset)
     flags = sess.env.status_flags()
     gather_ms = gatherer.gather_ms() if gatherer is not None else None
     # evidence that the collective saw every rank: a count all-reduce, and the last step's rewards summed two ways
     # (all-reduce of the local sums vs the sum of what the all-gather delivered)
     dist_info = {}
+    ring = gatherer is not None and gatherer.reward_every > 1
     if use_dist:
         ones = torch.ones(1, device=dev, dtype=torch.float64)
         dist.all_reduce(ones)
@@ -598,11 +604,17 @@ def worker(args):
                      'allreduce_rank_count': float(ones.item()), 'allreduce_reward_checksum': float(local_sum.item())}
         if gatherer is not None:
             all_reward, all_signal = gatherer.wait()
-            gsum = float(all_reward.double().sum().item())
+            if ring:                                          # [K, B_global] block: its last row is the last step only if the run ended on a block boundary
+                idx = total_steps - 1 - gatherer.reward_step
+                all_reward = all_reward[idx] if gatherer.reward_step >= 0 and 0 <= idx < gatherer.reward_every else None
+            gsum = float(all_reward.double().sum().item()) if all_reward is not None else float('nan')
             dist_info['allgather_reward_checksum'] = gsum
-            dist_info['allgather_envs'] = int(all_reward.numel())
+            dist_info['allgather_envs'] = int(all_reward.numel()) if all_reward is not None else 0
             dist_info['checksums_agree'] = bool(abs(gsum - dist_info['allreduce_reward_checksum'])
-                                                <= 1e-6 * max(1.0, abs(gsum)))
+                                                <= 1e-6 * max(1.0, abs(gsum))) if all_reward is not None else None
+            if all_reward is None:
+                dist_info['checksums_note'] = ('the last step is not the end of a gathered reward block (steps + warmup is not a multiple of '
+                                               '--reward-every): nothing to compare')
     # what the gather costs the step loop: the same steps again without it
     t_nogather = sess.timed(fence, None, args.with_reset) if gatherer is not None else None
 
@@ -632,7 +644,7 @@ def worker(args):
             tn = torch.tensor([t_nogather['dt']], device=dev, dtype=torch.float64)
             dist.all_reduce(tn, op=dist.ReduceOp.MAX)
             dist_info['gather'] = {
-                'mode': args.gather, 'signal_every': args.signal_every, 'backend': gatherer.backend,
+                'mode': args.gather, 'signal_every': args.signal_every, 'reward_every': gatherer.reward_every, 'backend': gatherer.backend,
                 'bytes_per_gpu_per_step': gatherer.bytes_per_signal_launch if args.signal_every == 1 else
                 gatherer.bytes_per_launch + (gatherer.bytes_per_signal_launch - gatherer.bytes_per_launch) / args.signal_every,
                 'gather_ms_per_step': gather_ms,                                   # side-stream events, rank 0
@@ -720,7 +732,7 @@ def core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer):
             entry = {'obs_mode': 'table (compact [B, N, 6] obs, no LinearObs expansion)', 'value': b * n * args.steps * world / dt,
                      'unit': 'agent-steps/s', 'ms_per_step': dt / args.steps * 1e3, 'roofline': sess.roofline(t)}
             if gatherer is not None:
-                entry['gather'] = {'mode': 'rewards', 'bytes_per_gpu_per_step': gatherer.bytes_per_launch,
+                entry['gather'] = {'mode': 'rewards', 'reward_every': gatherer.reward_every, 'bytes_per_gpu_per_step': gatherer.bytes_per_launch,
                                    'gather_ms_per_step': gatherer.gather_ms()}
             if not export:
                 entry['decoded_rb_pwr_export'] = ('off (d2d_set_export_actions(0)): info[rb] / info[tx_pwr_dbm] are the rollout\'s own '

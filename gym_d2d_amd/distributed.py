@@ -51,6 +51,11 @@ class StepGatherer:
     hop) would outlast ten times over; the learner then reads observations through `signal_every`.
     signal_every = K > 1: the (sinr, snr) columns ride along on every K-th launch only (the first included); `wait()` keeps
     returning the last gathered signal and `signal_step` says which launch it belongs to.
+    reward_every = K > 1 (mode 'rewards'): the host cost of ONE gather launch (stream hand-over, staging copy, collective: about 35 us
+    through torch.distributed, measured with one rank) is more than a whole compact-obs step (about 28 us at 4096 x 512), so a
+    per-step gather makes the step loop host bound.  With K > 1 every launch only copies the step's rewards into slot
+    (launch mod K) of a device-side ring - one small copy on the CURRENT stream, no stream hand-over - and every K-th launch
+    gathers the whole ring: `wait()` then returns the last K steps' rewards as [K, B_global] (row j = launch `reward_step` + j).
     per_agent_reward: gather rewards as [B, N] (Shannon / CueSinrShannon) instead of the env's scalar (SystemCapacity
     broadcasts one value to every agent, reward_fn.py:44: column 0 is all of it).
     timing: record CUDA events around every gather on the side stream; `gather_ms()` = mean ms per launch.
@@ -64,7 +69,7 @@ class StepGatherer:
 
     def __init__(self, b_local: int, n_links: int, device: torch.device, group=None, *, backend: str = 'torch',
                  handle=None, mode: str = 'table', signal_every: int = 1, per_agent_reward: bool = False,
-                 timing: bool = False) -> None:
+                 timing: bool = False, reward_every: int = 1) -> None:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -84,6 +89,10 @@ class StepGatherer:
             raise ValueError("mode must be 'table' or 'rewards'")
         if signal_every < 1:
             raise ValueError('signal_every must be >= 1')
+        if reward_every < 1 or (reward_every > 1 and (mode != 'rewards' or per_agent_reward)):
+            raise ValueError("reward_every > 1 needs mode='rewards' with per-env rewards")
+        self.reward_every = int(reward_every)
+        self.reward_step = -1                   # first launch of the gathered block (reward_every > 1)
         self.backend = backend
         self.handle = handle
         self.mode = mode
@@ -97,6 +106,11 @@ class StepGatherer:
             handle.comm_init(self.world, self.rank, box[0])
         f32 = torch.float32
         rshape = (b_local, n_links) if per_agent_reward else (b_local,)
+        if self.reward_every > 1:
+            # two rings: launches fill one while the other is being gathered
+            self.rings = [torch.zeros((self.reward_every, b_local), dtype=f32, device=device) for _ in range(2)]
+            self.all_ring = torch.zeros((self.world, self.reward_every, b_local), dtype=f32, device=device)
+            self._ring_free = [None, None]      # event: the gather that read this ring has finished
         self.stage_reward = torch.empty(rshape, dtype=f32, device=device)
         self.all_reward = torch.empty((self.world * b_local,) + rshape[1:], dtype=f32, device=device)
         self.stage_signal = self.all_signal = None
@@ -106,10 +120,11 @@ class StepGatherer:
         self.all_positions = torch.zeros((self.world * b_local, n_links, 4), dtype=f32, device=device)
         self.launches = 0
         self.signal_step = -1                   # index of the launch the gathered signal belongs to
-        self.bytes_per_launch = self.stage_reward.numel() * 4
+        self.bytes_per_launch = self.stage_reward.numel() * 4       # per step (reward_every > 1: K of them travel together)
         self.bytes_per_signal_launch = self.bytes_per_launch + (self.stage_signal.numel() * 4 if mode == 'table' else 0)
         self._timing = bool(timing) and self.cuda
         self._events = []
+        self._launch_mark = 0
         if self.cuda:
             self.comm_stream = torch.cuda.Stream(device=device)
             self.staged = torch.cuda.Event()
@@ -140,6 +155,8 @@ class StepGatherer:
     def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor = None) -> None:
         """Call right after the step was enqueued on the current stream.  reward_per_agent [B_local, N] (column 0
         is the env's scalar for SystemCapacity), table [B_local, N, 6] (mode 'table')."""
+        if self.reward_every > 1:
+            return self._launch_ring(reward_per_agent)
         with_signal = self.mode == 'table' and self.launches % self.signal_every == 0
         if with_signal and table is None:
             raise ValueError("mode 'table' gathers the (sinr, snr) columns: pass the obs table")
@@ -173,6 +190,37 @@ class StepGatherer:
         self.launches += 1
         self._pending = True
 
+    def _launch_ring(self, reward_per_agent: torch.Tensor) -> None:
+        k = self.reward_every
+        slot, which = self.launches % k, (self.launches // k) % 2
+        ring = self.rings[which]
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            if slot == 0 and self._ring_free[which] is not None:
+                cur.wait_event(self._ring_free[which])          # the gather that read this ring two blocks ago is done (long since)
+            ring[slot].copy_(reward_per_agent[:, 0])            # on the current stream: ordered with the step, no hand-over
+            if slot == k - 1:
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    if self._timing:
+                        e0 = torch.cuda.Event(enable_timing=True); e0.record(self.comm_stream)
+                    self._all_gather(self.all_ring.view(-1), ring.view(-1), self.comm_stream.cuda_stream)
+                    self.done.record(self.comm_stream)
+                    free = torch.cuda.Event(); free.record(self.comm_stream)
+                    self._ring_free[which] = free
+                    if self._timing:
+                        e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
+                        self._events.append((e0, e1))
+                self.reward_step = self.launches - (k - 1)
+                self._pending = True
+        else:
+            ring[slot].copy_(reward_per_agent[:, 0])
+            if slot == k - 1:
+                self._all_gather(self.all_ring.view(-1), ring.view(-1))
+                self.reward_step = self.launches - (k - 1)
+                self._pending = True
+        self.launches += 1
+
     def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(rewards [B_global] (or [B_global, N]), signal [B_global, N, 2] = sinr_dB, snr_dB - None in mode 'rewards') of
         the last launched gather, rank-major = global env order.  With signal_every > 1 the signal is that of launch
@@ -180,6 +228,9 @@ class StepGatherer:
         if self.cuda and self._pending:
             torch.cuda.current_stream(self.device).wait_event(self.done)
         self._pending = False
+        if self.reward_every > 1:
+            # [world, K, b_local] -> [K, B_global]: rank-major along the env axis = global env order
+            return self.all_ring.permute(1, 0, 2).reshape(self.reward_every, -1), None
         return self.all_reward, self.all_signal
 
     def table(self) -> torch.Tensor:
@@ -195,13 +246,14 @@ class StepGatherer:
         if not self._events:
             return 0.0
         self._events[-1][1].synchronize()
-        ms = sum(e0.elapsed_time(e1) for e0, e1 in self._events) / len(self._events)
-        return ms
+        launches = max(1, self.launches - self._launch_mark)      # reward_every > 1: one gather per K launches
+        return sum(e0.elapsed_time(e1) for e0, e1 in self._events) / launches
 
     def reset_timing(self) -> None:
         if self._events:
             self._events[-1][1].synchronize()
         self._events = []
+        self._launch_mark = self.launches
 
 
 def expand_table(table: torch.Tensor, handle=None, out: torch.Tensor = None) -> torch.Tensor:

@@ -126,6 +126,20 @@ def _modes_worker(rank, world, port, out_dir):
         want_sig = torch.cat([local(r, last)[1][:, :, 4:6] for r in range(world)])
         if not torch.equal(rew, want) or not torch.equal(sig, want_sig) or g.signal_step != last:
             errors.append(f'signal_every step {step}')
+    # rewards ride in a device-side ring and travel every 3rd launch: [3, B_global] blocks, rank-major along the env axis
+    g = StepGatherer(b, n, dev, mode='rewards', reward_every=3)
+    for step in range(7):
+        g.launch(*local(rank, step))
+        if step % 3 == 2:
+            block, sig = g.wait()
+            want = torch.stack([torch.cat([local(r, s)[0][:, 0] for r in range(world)]) for s in range(step - 2, step + 1)])
+            if sig is not None or g.reward_step != step - 2 or not torch.equal(block, want):
+                errors.append(f'reward ring block ending at step {step}')
+    try:
+        StepGatherer(b, n, dev, reward_every=2)          # mode 'table': not allowed
+        errors.append('reward_every with mode table did not raise')
+    except ValueError:
+        pass
     (Path(out_dir) / f'rank{rank}.txt').write_text('; '.join(errors) or 'ok')
     dist.barrier()
     dist.destroy_process_group()
@@ -193,12 +207,12 @@ def test_bench_self_launches_eight_ranks():
     """BASELINE config 5's world size through the launcher and the gather plumbing (stub handle, gloo), with the
     rewards-only gather plan."""
     r, out = _run_bench(['--gpus', '8', '--stub-cpu', '--steps', '3', '--warmup', '1', '--envs', '2', '--workload', 'default',
-                         '--gather', 'rewards'], timeout=600)
+                         '--gather', 'rewards', '--reward-every', '4'], timeout=600)      # 1 + 3 launches = one ring block
     assert r.returncode == 0, r.stderr[-2000:]
     line = out[0]
     assert line['n_gpus'] == 8 and line['rccl_ranks'] == 8 and line['allreduce_rank_count'] == 8.0
     assert line['allgather_envs'] == 16 and line['checksums_agree'] is True and len(line['per_rank']) == 8
-    assert line['gather']['mode'] == 'rewards' and line['gather']['bytes_per_gpu_per_step'] == 2 * 4
+    assert line['gather']['mode'] == 'rewards' and line['gather']['bytes_per_gpu_per_step'] == 2 * 4 and line['gather']['reward_every'] == 4
     assert abs(line['value_per_gpu'] * 8 - line['value']) < 1e-6 * line['value']
 
 

@@ -66,6 +66,14 @@ def _rank(rank, world, port, out_dir):
         torch.cuda.synchronize()
         assert s2 is None and np.array_equal(r2.cpu().numpy(), outs[k][0]) and np.array_equal(r3.cpu().numpy(), outs[k][0])
         assert g3.signal_step == (k // 2) * 2 and np.array_equal(g3.table().cpu().numpy(), outs[(k // 2) * 2][1])
+    # rewards in a device-side ring, gathered every 3rd launch
+    g4 = StepGatherer(end - first, 14, dev, mode='rewards', reward_every=3)
+    for k in range(STEPS):
+        env.step(torch.as_tensor(_actions(k, first, end - first), device=dev))
+        g4.launch(env._t['reward'])
+    block, _ = g4.wait()
+    torch.cuda.synchronize()
+    assert g4.reward_step == 0 and np.array_equal(block.cpu().numpy(), np.stack([outs[k][0] for k in range(STEPS)]))
     if rank == 0:
         np.savez(Path(out_dir) / 'gathered.npz', **{f'{name}{k}': arr for k, o in enumerate(outs)
                                                     for name, arr in zip(('reward', 'table', 'obs'), o)})
@@ -132,11 +140,12 @@ def test_bench_native_gather_backend_with_one_rank():
     import json
     import subprocess
     cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '1', '--force-dist', '--gather-backend', 'native', '--envs', '64',
-           '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-single-env-latency']
+           '--steps', '4', '--warmup', '1', '--reward-every', '2', '--no-cpu-baseline', '--no-single-env-latency']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
                        env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
     assert line['rccl_ranks'] == 1 and line['checksums_agree'] is True and line['gather']['backend'] == 'native'
     assert line['allgather_envs'] == 64 and line['gather']['gather_ms_per_step'] > 0
-    assert line['core_mode']['gather']['mode'] == 'rewards' and line['core_mode']['gather']['gather_ms_per_step'] > 0
+    assert line['core_mode']['gather']['mode'] == 'rewards' and line['core_mode']['gather']['reward_every'] == 2
+    assert line['core_mode']['gather']['gather_ms_per_step'] > 0
