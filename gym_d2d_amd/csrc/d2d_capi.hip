@@ -409,6 +409,9 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         W = (N + 31) / 32;
         if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) W = 0;
     }
+    // masks that do not fit (thousands of RBs): the lists are 20 bytes per RB instead of 4 per RB and 32 links - take them when
+    // nobody chose a search variant
+    if (W == 0 && !lists && h->tune_step_walk < 0 && h->bucketing && lpt > 0 && s.reward_fn != D2D_REWARD_CUE_SINR_SHANNON) { lists = 1; s.walk = 2; }
     if (lists && d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) { lists = 0; s.walk = 0; }
     s.lpt = lpt;
     d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, &s.lds);

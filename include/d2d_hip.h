@@ -176,7 +176,9 @@ typedef enum d2d_tuning {
     D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
     D2D_TUNE_OBS_BLOCK = 3,        /* threads per obs workgroup; 0 = auto                            */
     D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): T staged in LDS; 1: T read from global (A/B)      */
-    D2D_TUNE_STEP_THREADS = 5,     /* threads per ENV in the step kernel; 0 = auto (one per link)    */
+    D2D_TUNE_STEP_THREADS = 5,     /* threads per ENV in the step kernel; 0 = auto (one per link).  Below half the link
+                                      count no link sits in registers (strided kernel) and the per-RB search
+                                      structures give way to the O(N^2) sweep                              */
     D2D_TUNE_STEP_ENVS_PER_WG = 6, /* envs sharing one step workgroup; 0 = auto                      */
     D2D_TUNE_STEP_BLOCK = 7,       /* threads per step workgroup (>= envs * threads/env); 0 = auto   */
     D2D_TUNE_STEP_FUSE_OBS = 8,    /* LinearObs expansion inside the step launch: 1 on, 0 off,
