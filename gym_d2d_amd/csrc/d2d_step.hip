@@ -968,41 +968,75 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     if (!FULL && (HOT == 2 || a.fuse_obs)) {
         const unsigned T = blockDim.x, q_per_row = a.obs_q_per_row, total = (unsigned)N * q_per_row;
         const unsigned row_floats = 6u * (unsigned)N;
-        const unsigned RP = T / q_per_row;                  // whole obs rows one pass of the workgroup covers
-        if (HOT == 2 || (a.fuse_obs == 4 && RP >= 1u)) {
-            // Fixed (row-in-pass r, float4 column q) per thread: the source of output column f in row i is 6i + f for f < 6
-            // (the agent's own six values), else f - 6 once i >= f / 6 (links before the agent shift by one slot), else f.
-            // Thresholds and both candidates are per-thread constants, so a store costs two compares + selects instead of
-            // a 40-bit multiply-shift division and two three-way selections (the expansion was VALU bound at N = 50).
-            const unsigned r = (unsigned)(((unsigned long long)tid * a.obs_q_magic) >> 40), q = tid - r * q_per_row;
-            const bool worker = r < RP;
-            const unsigned f0 = q * 4u, f1 = f0 + 2u;
-            const unsigned t0 = f0 / 6u, t1 = f1 / 6u;       // by the compiler's multiply-shift: constants of the thread
-            const bool own0 = f0 < 6u, own1 = f1 < 6u;
-            // All workgroups are resident at once and reach this point together; each owns one contiguous region (epw envs x
-            // N rows).  Walked from its start by everyone, the chip's concurrent stores sit a fixed stride apart (one region)
-            // and, depending on where the allocation landed physically, pile onto a subset of the HBM channels (14.9 ... 17.4
-            // us per step for the SAME launch across allocations, tools/probes/context_effect.py).  So every workgroup starts
-            // at its own phase of the (env, pass) sequence and wraps around: the concurrent addresses are decorrelated.
-            const unsigned passes = ((unsigned)N + RP - 1u) / RP;
+        if (HOT == 2 || a.fuse_obs == 4) {
+            // The obs blocks of this workgroup's envs are ONE contiguous region of n_el * N * q_per_row float4: a pass of the
+            // workgroup is T consecutive float4 of it (every lane stores in every pass but the last; at N = 50 a row is 75 float4,
+            // so a row-aligned pass would leave 31 of 256 lanes idle).  A lane's position (env, row, column) is carried as
+            // (LDS byte address of the env's T, 6 * row, float column) and ADVANCED by the pass's constant step with two
+            // conditional wraps - no division, no per-pass pointer rebuild, one 32-bit byte offset against an SGPR base for the
+            // store.  The two ds_read_b64 of pass t + 1 are issued before the store of pass t (the wave is alone on its SIMD at
+            // 256 threads per CU: nothing else hides the LDS round trip).
+            //   source of output column f (even) in row i: 6i + f if f < 6 (the agent's own six values), f - 6 if f < 6i + 6
+            //   (links before the agent shift by one slot), else f - obs_fn.py:43-53, same mapping as csrc/d2d_obs.hip.
             const unsigned n_el = min((unsigned)a.epw, (unsigned)a.B - blockIdx.x * (unsigned)a.epw);
-            const unsigned total_it = n_el * passes;
-            unsigned it0 = a.obs_rotate ? (blockIdx.x * (unsigned)a.obs_rotate) % total_it : 0u;
-            unsigned el = it0 / passes, ps = it0 - el * passes;
-            for (unsigned t = 0; t < total_it; ++t) {
-                const f32x2* t2 = reinterpret_cast<const f32x2*>(smem_raw + el * a.lds.env_bytes + a.lds.tflat);
-                f32x4* out = reinterpret_cast<f32x4*>(a.obs + (size_t)(blockIdx.x * (unsigned)a.epw + el) * N * row_floats) + q;
-                const unsigned i = r + ps * RP;
-                if (worker && i < (unsigned)N) {
-                    const unsigned head = 6u * i;
-                    const unsigned s0 = own0 ? head + f0 : (i >= t0 ? f0 - 6u : f0);
-                    const unsigned s1 = own1 ? head + f1 : (i >= t1 ? f1 - 6u : f1);
-                    const f32x2 lo = t2[s0 >> 1], hi = t2[s1 >> 1];
-                    const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
-                    __builtin_nontemporal_store(v, out + (size_t)i * q_per_row);
+            const unsigned region = n_el * total;                              // float4 of the whole region
+            const unsigned full = region / T;                                  // passes in which every lane stores
+            const unsigned passes = full + (region - full * T != 0u ? 1u : 0u);
+            // the pass step T float4 = de envs + dr rows + dq columns (de = 0 unless an env is smaller than a pass)
+            const unsigned de = T / total, rem_e = T - de * total;
+            const unsigned dr = (unsigned)(((unsigned long long)rem_e * a.obs_q_magic) >> 40), dq = rem_e - dr * q_per_row;
+            const unsigned step_f = 4u * dq, step_head = 6u * dr, step_lds = de * a.lds.env_bytes;
+            unsigned char* const out_base = reinterpret_cast<unsigned char*>(a.obs + (size_t)(blockIdx.x * (unsigned)a.epw) * N * row_floats);
+            // All workgroups are resident at once and reach this point together; walked from its start by everyone, the chip's
+            // concurrent stores sit one fixed stride apart.  Every workgroup starts at its own pass and wraps around (two segments).
+            const unsigned p0 = a.obs_rotate ? (blockIdx.x * (unsigned)a.obs_rotate) % passes : 0u;
+            struct Cur { unsigned lds, head, f; };
+            const auto locate = [&](unsigned idx) {                           // once per segment: the only divisions
+                const unsigned el = idx / total, in_env = idx - el * total;
+                const unsigned i = (unsigned)(((unsigned long long)in_env * a.obs_q_magic) >> 40), q = in_env - i * q_per_row;
+                Cur c; c.lds = el * a.lds.env_bytes + a.lds.tflat; c.head = 6u * i; c.f = 4u * q;
+                return c;
+            };
+            const auto advance = [&](Cur c) {
+                c.f += step_f;
+                const bool cw = c.f >= row_floats;
+                c.f -= cw ? row_floats : 0u;
+                c.head += step_head + (cw ? 6u : 0u);
+                const bool rw = c.head >= row_floats;
+                c.head -= rw ? row_floats : 0u;
+                c.lds += step_lds + (rw ? a.lds.env_bytes : 0u);
+                return c;
+            };
+            const auto fetch = [&](const Cur& c) {
+                const unsigned f1 = c.f + 2u, lim = c.head + 6u;
+                const unsigned s0 = c.f < 6u ? c.head + c.f : (c.f < lim ? c.f - 6u : c.f);
+                const unsigned s1 = f1 < 6u ? c.head + f1 : (f1 < lim ? f1 - 6u : f1);
+                const f32x2 lo = *reinterpret_cast<const f32x2*>(smem_raw + c.lds + s0 * 4u);
+                const f32x2 hi = *reinterpret_cast<const f32x2*>(smem_raw + c.lds + s1 * 4u);
+                const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+                return v;
+            };
+            const auto segment = [&](unsigned begin, unsigned end) {           // whole passes [begin, end): no predication
+                if (begin >= end) return;
+                unsigned off = (begin * T + (unsigned)tid) * 16u;
+                Cur c = locate(begin * T + (unsigned)tid);
+                f32x4 v = fetch(c);
+#pragma unroll 2
+                for (unsigned p = begin + 1u; p < end; ++p) {
+                    c = advance(c);
+                    const f32x4 vn = fetch(c);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_base + off));
+                    off += T * 16u;
+                    v = vn;
                 }
-                if (++ps == passes) { ps = 0u; if (++el == n_el) el = 0u; }
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_base + off));
+            };
+            segment(p0 < full ? p0 : full, full);
+            if (passes != full) {                                              // the region's tail: part of the lanes
+                const unsigned idx = full * T + (unsigned)tid;
+                if (idx < region) __builtin_nontemporal_store(fetch(locate(idx)), reinterpret_cast<f32x4*>(out_base + (size_t)idx * 16u));
             }
+            segment(0u, p0 < full ? p0 : full);
         } else if (HOT != 2) {
             for (int el = 0; el < a.epw; ++el) {
                 const int be = blockIdx.x * a.epw + el;
@@ -1088,7 +1122,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
                       a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 && a.mask_words > 0 &&
-                      a.fuse_obs == 4 && a.obs_q_per_row > 0 && (unsigned)block_threads / a.obs_q_per_row >= 1u &&
+                      a.fuse_obs == 4 && a.obs_q_per_row > 0 &&
                       (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
