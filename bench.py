@@ -191,11 +191,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, rank_timeout=0.0):
     """Start one rank process per GPU and wait for them.  This process never touches HIP (torch is not even imported
     here) and never execs: the ranks are ordinary children.  Rank 0 inherits stdout (the JSON line); the other ranks'
-    stdout goes to stderr.  Returns the exit code (first failing rank's, else 0)."""
+    stdout goes to stderr.  Returns the exit code (first failing rank's, else 0).  rank_timeout > 0: a deadline in seconds
+    for the whole job - a rank stuck in a collective would otherwise hold the job until the driver's own limit; on expiry
+    the launcher terminates ITS OWN children by PID (kill after a grace period) and returns 124."""
     port = os.environ.get('MASTER_PORT') or str(_free_port())
+    deadline = time.monotonic() + rank_timeout if rank_timeout > 0 else None
     procs = []
     for rank in range(n):
         env = dict(os.environ)
@@ -217,6 +220,19 @@ def launch_ranks(n, argv):
                 print(f'bench launcher: rank {rank} exited with {rc}; stopping the other ranks', file=sys.stderr)
                 for other in live:
                     procs[other].terminate()            # exact PIDs of our own children
+        if deadline is not None and live and time.monotonic() > deadline:
+            print(f'bench launcher: ranks {sorted(live)} still running after --rank-timeout {rank_timeout:g} s; terminating them',
+                  file=sys.stderr)
+            for rank in live:
+                procs[rank].terminate()
+            grace = time.monotonic() + 5.0
+            while any(procs[r].poll() is None for r in live) and time.monotonic() < grace:
+                time.sleep(0.05)
+            for rank in live:
+                if procs[rank].poll() is None:
+                    procs[rank].kill()
+                procs[rank].wait()
+            return 124
         time.sleep(0.05)
     return code
 
@@ -284,7 +300,7 @@ def parse_args(argv=None):
                     help="who drives the CUE links (default: the workload's own choice)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the per-step all-gather')
-    ap.add_argument('--gather', default='table', choices=['table', 'rewards'],
+    ap.add_argument('--gather', default='table', choices=['table', 'rewards', 'planes'],
                     help="N > 1: what the per-step all-gather carries (StepGatherer mode): rewards + the (sinr, snr) columns of the "
                          "obs table, or rewards only")
     ap.add_argument('--gather-backend', default='torch', choices=['torch', 'native'],
@@ -297,10 +313,16 @@ def parse_args(argv=None):
     ap.add_argument('--force-dist', action='store_true', help='init RCCL and run the gather path even with one rank (test hook)')
     ap.add_argument('--no-single-env-latency', action='store_true',
                     help='N = 1 also times the drop-in single-env D2DEnv.step (host dicts in / out); this skips it')
+    ap.add_argument('--rank-timeout', type=float, default=1500.0,
+                    help='N > 1, self-launched ranks: seconds after which the launcher terminates its children and exits 124 '
+                         '(0 = no deadline)')
     ap.add_argument('--no-extras', action='store_true',
                     help='N = 1, default run: skip other_workloads / vec_env_step_ms / the write-ceiling probe (the headline only)')
     ap.add_argument('--no-export', action='store_true',
                     help='d2d_set_export_actions(0) for the measured session: no decoded (rb, pwr) planes (a rollout knows its actions)')
+    ap.add_argument('--reward-per-env', action='store_true',
+                    help="--obs table / none: SystemCapacity's reward once per env (VecD2DEnv(reward_per_env=True), D2D_REWARD_PER_ENV) "
+                         'instead of the [B, N] copy')
     ap.add_argument('--tune', default='', help='comma list key=value: rows,nt,xcd,bucket,block,threads,epw,sblock,fuse,walk')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST HOOK: no GPU, gloo backend, synthetic per-rank results - exercises only the launcher / gather plumbing')
@@ -314,10 +336,12 @@ GROUP = 20          # launches per HIP-event pair when a step is a single kernel
 CORE_BYTES = 40.0   # action 4 + positions 16 + outputs 16 + reward 4, per agent-step
 
 
-def algorithmic_bytes(n, obs):
+def algorithmic_bytes(n, obs, reward_per_env=False):
     """Per agent-step: the 40 core bytes + 24 N for the materialised LinearObs (+ the 24 the expansion
-    reads) or + 24 for the compact table."""
-    return CORE_BYTES + (24.0 * n if obs == 'linear' else (24.0 if obs == 'table' else 0.0))
+    reads) or + 24 for the compact table.  reward_per_env: SystemCapacity's scalar once per env (4 / N bytes per link)
+    instead of the 4-byte copy every agent gets."""
+    core = CORE_BYTES - 4.0 + 4.0 / n if reward_per_env else CORE_BYTES
+    return core + (24.0 * n if obs == 'linear' else (24.0 if obs == 'table' else 0.0))
 
 
 class Session:
@@ -344,18 +368,18 @@ class Session:
         else:
             from gym_d2d_amd import _native
             from gym_d2d_amd.envs import VecD2DEnv
-            from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction
+            from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction, SignalPlanesObsFunction
             self.native = _native
             cfg = {'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': local,
-                   'obs_fn': LinearObsFunction if obs == 'linear' else OwnLinkObsFunction}
+                   'obs_fn': {'linear': LinearObsFunction, 'table': OwnLinkObsFunction, 'none': SignalPlanesObsFunction}[obs]}
             if w.get('plugin'):
                 from gym_d2d_amd.path_loss import FreeSpacePathLoss
                 cfg['path_loss_model'] = FreeSpacePathLoss
-            self.env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b, cue_actions=self.cue_mode, export_actions=export)
+            self.reward_per_env = bool(getattr(args, 'reward_per_env', False)) and obs != 'linear'
+            self.env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b, cue_actions=self.cue_mode, export_actions=export,
+                                 reward_per_env=self.reward_per_env)
             self.h = h = self.env.simulator.handle
             self.n_agents = self.env.num_agents
-            if obs == 'none':
-                h.set_obs_mode(_native.OBS_NONE)
             tune_keys = {'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
                          'xcd': _native.TUNE_OBS_XCD_REMAP, 'block': _native.TUNE_OBS_BLOCK,
                          'threads': _native.TUNE_STEP_THREADS, 'epw': _native.TUNE_STEP_ENVS_PER_WG,
@@ -383,7 +407,7 @@ class Session:
         # over the same steps brackets GROUPS of back-to-back launches with one event pair (on the stream the kernels run
         # on): average launch duration = group time / launches, inter-launch gaps included.
         self.events_in_timed = self.obs == 'linear' and self.n > 128
-        self.raw_handle = obs == 'none'                  # VecD2DEnv has no obs-less mode: the handle's obs mode is switched under it
+        self.raw_handle = False                          # core_mode switches the handle's obs mode under the env and sets this
 
     def run(self, k0, k1, gatherer=None, with_reset=False):
         """Steps k0 .. k1-1 through the PUBLIC batched API, VecD2DEnv.step(actions) -> (obs, rewards, dones, info) (the C-ABI
@@ -395,10 +419,17 @@ class Session:
             if new_episode:                              # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
                 h.reset_positions(1234, k // 10)
             step(actions[k])
+            planes = getattr(self, 'planes_gather', None)
             if gatherer is not None and (new_episode or k == 0):
-                gatherer.gather_positions(env._t['table'])      # position columns only change at reset (not per step)
-            if gatherer is not None:
-                gatherer.launch(env._t['reward'], env._t['table'])
+                # position columns only change at reset (not per step); planes plan: the library's own link rows
+                gatherer.gather_positions(planes[3]() if planes else (env.link_positions() if self.obs == 'none' else env._t['table']))
+            if gatherer is not None and planes:
+                gatherer.launch(planes[0], sinr=planes[1], snr=planes[2])
+            elif gatherer is not None:
+                if self.obs == 'none':
+                    gatherer.launch(env._t['reward'], sinr=env._t['sinr_db'], snr=env._t['snr_db'])
+                else:
+                    gatherer.launch(env._t['reward'], env._t['table'])
         if gatherer is not None:
             gatherer.wait()
 
@@ -449,7 +480,7 @@ class Session:
             avg_ms = t['obs_ms'] / t['obs_n']
             roof = {'kernel': 'obs_expand_kernel'}
         else:
-            per_launch = b * n * algorithmic_bytes(n, self.obs)
+            per_launch = b * n * algorithmic_bytes(n, self.obs, getattr(self, 'reward_per_env', False))
             avg_ms = t['step_ms'] / max(t['step_n'], 1)
             roof = {'kernel': 'step_kernel'}
         ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -460,7 +491,8 @@ class Session:
                                      'library stream, in a second pass over the same steps; the timed region itself runs '
                                      'without events')})
         if not self.stub:
-            attach_traffic(roof, self.key, self.obs, bool(self.args.envs), self.current_export())
+            attach_traffic(roof, self.key, self.obs + ('_per_env_reward' if getattr(self, 'reward_per_env', False) else ''),
+                           bool(self.args.envs), self.current_export())
         return roof
 
     def current_export(self):
@@ -520,6 +552,8 @@ def worker(args):
         raise SystemExit(f'WORLD_SIZE={world} but --gpus {args.gpus}')
     if os.environ.get('D2D_BENCH_TEST_FAIL_RANK') == str(rank):       # test hook: a rank that dies must fail the job
         raise SystemExit(3)
+    if os.environ.get('D2D_BENCH_TEST_HANG_RANK') == str(rank):       # test hook: a rank that never returns must not hold the job
+        time.sleep(3600)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     stub = args.stub_cpu
     w = dict(WORKLOADS[args.workload])
@@ -566,6 +600,7 @@ def worker(args):
         single_ms = {'25 CUE + 25 DUE pairs, 25 RB (reference default env)': single_env_latency(25, 25, 25, local)}
         if (c, p, r) != (25, 25, 25):
             single_ms[f'{c} CUE + {p} DUE pairs, {r} RB'] = single_env_latency(c, p, r, local)
+            single_ms[f'{c} CUE + {p} DUE pairs, {r} RB, custom Python PathLoss (table route)'] = custom_path_loss_cost(c, p, r, local)
 
     def fence():
         if not stub:
@@ -598,7 +633,8 @@ def worker(args):
     if use_dist:
         ones = torch.ones(1, device=dev, dtype=torch.float64)
         dist.all_reduce(ones)
-        local_sum = sess.env._t['reward'][:, 0].double().sum().reshape(1)
+        rew = sess.env._t['reward']
+        local_sum = (rew if rew.dim() == 1 else rew[:, 0]).double().sum().reshape(1)
         dist.all_reduce(local_sum)
         dist_info = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
                      'allreduce_rank_count': float(ones.item()), 'allreduce_reward_checksum': float(local_sum.item())}
@@ -679,7 +715,7 @@ def worker(args):
             'config': cfg,
             'roofline': roof,
             'kernels': {'step_kernel_ms': t['step_ms'] / max(t['step_n'], 1), 'obs_expand_kernel_ms': (t['obs_ms'] / t['obs_n']) if t['obs_n'] else None},
-            'algorithmic_bytes_per_agent_step': algorithmic_bytes(n, sess.obs),
+            'algorithmic_bytes_per_agent_step': algorithmic_bytes(n, sess.obs, getattr(sess, 'reward_per_env', False)),
             'status_flags': flags,
             'target_agent_steps_per_s': 1e7,
         }
@@ -699,6 +735,8 @@ def worker(args):
                 out[k] = extras[k]
         if cpu is not None:
             out['cpu_baseline'] = cpu
+        elif world > 1:
+            out['cpu_baseline'] = 'N=1 line only (the CPU port is timed on rank 0 of the one-GPU run)'
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)                 # the real stdout is back for the one line that belongs there
         print(json.dumps(out), flush=True)
@@ -740,6 +778,43 @@ def core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer):
                 out = entry
             else:
                 out['with_decoded_rb_pwr_export'] = {k: entry[k] for k in ('value', 'ms_per_step', 'roofline')}
+        # The learner configuration of SURVEY.md 8(e): no observation array at all (D2D_OBS_NONE - the (sinr, snr) planes ARE the
+        # per-step observation, positions once per reset from D2D_BUF_LINK_POS), the env's reward once per env
+        # (D2D_REWARD_PER_ENV), no decoded (rb, pwr) planes.  Its own algorithmic bytes: action 4 + positions 16 + four result
+        # planes 16 + 4 / N of reward = 36 per link and step.  With N > 1 the gather is StepGatherer(mode='planes').
+        h.set_obs_mode(_native.OBS_NONE)
+        h.set_export_actions(False)
+        h.set_reward_layout(_native.REWARD_PER_ENV)
+        sess.obs, sess.export_now, sess.reward_per_env = 'none', False, True
+        renv = torch.empty(b, dtype=torch.float32, device=dev)
+        h.bind_buffer(_native.BUF_REWARD_ENV, renv.data_ptr(), b * 4)
+        try:
+            gatherer = None
+            if use_dist:
+                from gym_d2d_amd.distributed import StepGatherer
+                gatherer = StepGatherer(b, n, dev, mode='planes', signal_every=max(args.signal_every, 1), timing=True)
+                sess.planes_gather = (renv, sess.env._t['sinr_db'], sess.env._t['snr_db'], sess.env.link_positions)
+            t = sess.timed(fence, gatherer)
+            dt = t['dt']
+            if use_dist:
+                import torch.distributed as dist
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            out['planes_only'] = {
+                'obs_mode': 'none (D2D_OBS_NONE: the sinr_db / snr_db planes are the per-step observation; positions once per reset '
+                            'from D2D_BUF_LINK_POS), reward once per env (D2D_REWARD_PER_ENV), no decoded (rb, pwr) planes',
+                'value': b * n * args.steps * world / dt, 'unit': 'agent-steps/s', 'ms_per_step': dt / args.steps * 1e3,
+                'algorithmic_bytes_per_agent_step': algorithmic_bytes(n, 'none', True), 'roofline': sess.roofline(t)}
+            if gatherer is not None:
+                out['planes_only']['gather'] = {'mode': 'planes', 'signal_every': gatherer.signal_every,
+                                                'bytes_per_gpu_per_step': gatherer.bytes_per_signal_launch,
+                                                'gather_ms_per_step': gatherer.gather_ms()}
+        finally:
+            sess.planes_gather = None
+            sess.reward_per_env = False
+            h.set_reward_layout(_native.REWARD_PER_AGENT)
+            h.bind_buffer(_native.BUF_REWARD_ENV, 0, 0)
     finally:
         h.set_export_actions(True)
         sess.export_now = sess.export
@@ -842,11 +917,41 @@ def single_env_latency(c, p, r, ordinal, steps=200):
     return ms
 
 
+def custom_path_loss_cost(c, p, r, ordinal):
+    """A user PathLoss that only defines __call__ (examples/custom_path_loss.py:8-16) goes through the host-evaluated table:
+    what reset() costs then (the (link transmitter) x (link receiver) pairs evaluated in Python, path_loss.py table_db) and
+    what a step costs afterwards."""
+    import math
+    from gym_d2d_amd.envs import D2DEnv
+    from gym_d2d_amd.path_loss import PathLoss
+
+    class FooPathLoss(PathLoss):
+        def __call__(self, tx, rx):
+            d = tx.position.distance(rx.position)
+            return 20 * math.log10(d) - tx.tx_antenna_gain_dBi - rx.rx_antenna_gain_dBi
+    env = D2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'device_ordinal': ordinal, 'path_loss_model': FooPathLoss})
+    obs = env.reset()
+    t0 = time.perf_counter()
+    obs = env.reset()
+    reset_ms = (time.perf_counter() - t0) * 1e3
+    rng = np.random.default_rng(0)
+    act = {k: int(rng.integers(0, env.action_space['due' if k.startswith('due') else 'cue'].n)) for k in obs}
+    env.step(act)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        env.step(act)
+    step_ms = (time.perf_counter() - t0) / 10 * 1e3
+    calls = len(set(env.simulator.link_tx.tolist())) * len(set(env.simulator.link_rx.tolist()))
+    env.close()
+    return {'reset_ms': reset_ms, 'step_ms': step_ms, 'path_loss_calls_per_reset': calls,
+            'device_pairs_an_all_pairs_table_would_evaluate': (1 + c + 2 * p) ** 2}
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if args.gpus > 1 and 'RANK' not in os.environ:
-        sys.exit(launch_ranks(args.gpus, argv))
+        sys.exit(launch_ranks(args.gpus, argv, args.rank_timeout))
     worker(args)
 
 

@@ -9,7 +9,7 @@ from typing import Optional
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libd2d_hip.so'
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LINKS = 2048
 
 # d2d_status
@@ -22,12 +22,14 @@ REWARD_NONE, REWARD_SYSTEM_CAPACITY, REWARD_SHANNON, REWARD_CUE_SINR_SHANNON = 0
 OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
 # d2d_buffer
 (BUF_POS_X, BUF_POS_Y, BUF_ACTIONS, BUF_RB, BUF_PWR, BUF_SINR_DB, BUF_SNR_DB, BUF_RATE_BPS, BUF_CAPACITY,
- BUF_REWARD, BUF_OBS_TABLE, BUF_OBS, BUF_ENV_FLAGS, BUF_COUNT) = range(14)
+ BUF_REWARD, BUF_OBS_TABLE, BUF_OBS, BUF_ENV_FLAGS, BUF_LINK_POS, BUF_REWARD_ENV, BUF_COUNT) = range(16)
 FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
 (TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK, TUNE_OBS_VARIANT,
  TUNE_STEP_THREADS, TUNE_STEP_ENVS_PER_WG, TUNE_STEP_BLOCK, TUNE_STEP_FUSE_OBS, TUNE_STEP_ABLATE,
  TUNE_STEP_WALK, TUNE_STEP_PREFETCH, TUNE_STEP_LPT, TUNE_STEP_NT_RESULTS, TUNE_STEP_SCALAR_RECORDS,
- TUNE_STEP_OBS_ROTATE) = range(16)
+ TUNE_STEP_OBS_ROTATE, TUNE_OBS_STAGGER) = range(17)
+# d2d_reward_layout
+REWARD_PER_AGENT, REWARD_PER_ENV = 0, 1
 UNIQUE_ID_BYTES = 128
 
 BUFFER_DTYPES = {BUF_ACTIONS: np.int32, BUF_RB: np.int32, BUF_PWR: np.int32, BUF_ENV_FLAGS: np.int32}
@@ -71,13 +73,14 @@ SIGNATURES = {
     'd2d_synchronize': (C.c_int, [_P]),
     'd2d_set_device_table': (C.c_int, [_P, _I, _DP, _DP, _DP, _DP, _DP]),
     'd2d_set_path_loss_power_law': (C.c_int, [_P, _I, _DP, _DP, _DP]),
-    'd2d_set_path_loss_table': (C.c_int, [_P, _FP, _I]),
+    'd2d_set_path_loss_table': (C.c_int, [_P, _DP, _I]),
     'd2d_set_path_loss_shadowing': (C.c_int, [_P, _I, _DP, _DP, _DP, C.c_double, C.c_double, C.c_uint64]),
     'd2d_set_links': (C.c_int, [_P, _I, _IP, _IP, _IP]),
     'd2d_set_fixed_actions': (C.c_int, [_P, _I, _IP, _IP, _IP]),
     'd2d_positions_changed': (C.c_int, [_P]),
     'd2d_set_reward': (C.c_int, [_P, _I, C.c_float]),
     'd2d_set_obs_mode': (C.c_int, [_P, _I]),
+    'd2d_set_reward_layout': (C.c_int, [_P, _I]),
     'd2d_set_bucketing': (C.c_int, [_P, _I]),
     'd2d_set_export_actions': (C.c_int, [_P, _I]),
     'd2d_set_tuning': (C.c_int, [_P, _I, _I]),
@@ -102,6 +105,7 @@ SIGNATURES = {
     'd2d_profile_reset': (C.c_int, [_P]),
     'd2d_probe_write_bandwidth': (C.c_int, [_P, C.c_size_t, _I, C.POINTER(C.c_double)]),
     'd2d_probe_write_variants': (C.c_int, [_P, C.c_size_t, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
+    'd2d_probe_write_staged': (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -185,11 +189,11 @@ class Handle:
                                                      float(d0_m), float(chi_db), C.c_uint64(seed)))
 
     def set_path_loss_table(self, pl_db: np.ndarray) -> None:
-        t = np.ascontiguousarray(pl_db, dtype=np.float32)
+        t = np.ascontiguousarray(pl_db, dtype=np.float64)        # dB as the plugin returned them; rounded once, as linear gains
         d = self.num_devices
         if t.shape not in ((d, d), (self.num_envs, d, d)):
             raise ValueError(f'path-loss table must be [{d},{d}] or [{self.num_envs},{d},{d}], got {t.shape}')
-        _check(self._lib.d2d_set_path_loss_table(self._h, t.ctypes.data_as(_FP), int(t.ndim == 3)))
+        _check(self._lib.d2d_set_path_loss_table(self._h, _dptr(t), int(t.ndim == 3)))
 
     def set_links(self, tx_dev, rx_dev, link_type) -> None:
         a = [np.ascontiguousarray(c, dtype=np.int32) for c in (tx_dev, rx_dev, link_type)]
@@ -216,6 +220,10 @@ class Handle:
     def set_obs_mode(self, mode: int) -> None:
         _check(self._lib.d2d_set_obs_mode(self._h, mode))
 
+    def set_reward_layout(self, layout: int) -> None:
+        """REWARD_PER_ENV: SystemCapacity's scalar once per env (BUF_REWARD_ENV [B]) instead of N copies (BUF_REWARD [B,N])."""
+        _check(self._lib.d2d_set_reward_layout(self._h, layout))
+
     def set_bucketing(self, enabled: bool) -> None:
         _check(self._lib.d2d_set_bucketing(self._h, int(enabled)))
 
@@ -234,8 +242,10 @@ class Handle:
             return (b, n, 6)
         if which == BUF_OBS:
             return (b, n, 6 * n)
-        if which == BUF_ENV_FLAGS:
+        if which in (BUF_ENV_FLAGS, BUF_REWARD_ENV):
             return (b,)
+        if which == BUF_LINK_POS:
+            return (b, n, 4)
         if which == BUF_ACTIONS:
             return (b, n - self.num_fixed)
         return (b, n)
@@ -367,4 +377,11 @@ class Handle:
     def probe_write_bandwidth(self, nbytes: int, iters: int = 10) -> float:
         g = C.c_double()
         _check(self._lib.d2d_probe_write_bandwidth(self._h, nbytes, iters, C.byref(g)))
+        return g.value
+
+    def probe_write_staged(self, nbytes: int, variant: int, stagger: int = 0, iters: int = 5, dst_ptr: int = 0) -> float:
+        """GB/s of one fill variant with the obs kernel's timing structure (+32: LDS stage + barrier, +64: per-wave sleep
+        stagger); dst_ptr = 0 writes a scratch buffer, else that device memory - see d2d_probe_write_staged."""
+        g = C.c_double()
+        _check(self._lib.d2d_probe_write_staged(self._h, _P(dst_ptr or None), nbytes, variant, stagger, iters, C.byref(g)))
         return g.value

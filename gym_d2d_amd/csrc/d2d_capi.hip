@@ -95,7 +95,8 @@ struct d2d_handle {
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
     int export_actions = 1;                          // d2d_step writes the decoded (rb, pwr) to D2D_BUF_RB / D2D_BUF_PWR
-    int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0;
+    int reward_layout = D2D_REWARD_PER_AGENT;        // SystemCapacity: [B,N] rows or one scalar per env (D2D_BUF_REWARD_ENV)
+    int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0, tune_stagger = 0;
     int num_cus = 0;
     int tune_step_prefetch = -1;                     // action prefetch distance in envs: -1 auto, 0 off
     int tune_step_obs_rotate = -1;                   // fused expansion start-phase multiplier: -1 auto (29), 0 off
@@ -108,6 +109,7 @@ struct d2d_handle {
     // RCCL communicator (d2d_comm_init)
     void* comm = nullptr;
     int comm_world = 0, comm_rank = 0;
+    bool comm_used = false;                          // a d2d_allgather has been enqueued on the communicator
     unsigned long long env_offset = 0;
     double shadow_chi = 0, shadow_d0 = 0;
     unsigned long long shadow_seed = 0, shadow_step = 0;
@@ -129,12 +131,14 @@ size_t active_bytes(const d2d_handle* h, int which, int n_links) {
         case D2D_BUF_POS_X: case D2D_BUF_POS_Y: return B * D * 4;
         case D2D_BUF_OBS_TABLE: return B * N * 6 * 4;
         case D2D_BUF_OBS: return B * N * 6 * N * 4;
-        case D2D_BUF_ENV_FLAGS: return B * 4;
+        case D2D_BUF_ENV_FLAGS: case D2D_BUF_REWARD_ENV: return B * 4;
+        case D2D_BUF_LINK_POS: return B * N * 16;
         default: return B * N * 4;
     }
 }
 
 int ensure_buffer(d2d_handle* h, int which, void** out) {
+    if (which == D2D_BUF_LINK_POS) { *out = h->lpos; return D2D_OK; }      // library-owned, sized at d2d_create
     Buffer& bf = h->buf[which];
     const size_t need = active_bytes(h, which, which == D2D_BUF_OBS ? h->N : h->Nmax);
     if (bf.ptr && bf.bytes >= need) { *out = bf.ptr; return D2D_OK; }
@@ -337,6 +341,7 @@ void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float*
     o.nontemporal = h->tune_nt;
     o.block = block;
     o.variant = h->tune_variant;
+    o.stagger = h->tune_stagger;
     o.table = table;
     o.obs = obs;
     *out = o;
@@ -374,7 +379,11 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         s.dbg = h->dbg;
     }
 #endif
-    s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (N > 1024 ? 2 : 0);   // masks cover N <= 1024; beyond, the member lists
+    // masks cover N <= 1024; beyond that the member lists (eight slots per RB) - but only where they can hold the env: with more
+    // than four links per RB on average a ninth link on some RB is the rule, the list build is wasted and the workgroup
+    // sweeps all pairs anyway (N > 8 R: by pigeonhole), so those shapes go straight to the sweep
+    const bool lists_can_help = (long long)N <= 4ll * h->cfg.num_rbs;
+    s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (N > 1024 && lists_can_help ? 2 : 0);
 
     // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
     // workgroup (N = 50: four 64-thread envs in 256 threads), and for small N the LinearObs expansion runs inside the
@@ -411,7 +420,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     }
     // masks that do not fit (thousands of RBs): the lists are 20 bytes per RB instead of 4 per RB and 32 links - take them when
     // nobody chose a search variant
-    if (W == 0 && !lists && h->tune_step_walk < 0 && h->bucketing && lpt > 0 && s.reward_fn != D2D_REWARD_CUE_SINR_SHANNON) { lists = 1; s.walk = 2; }
+    if (W == 0 && !lists && lists_can_help && h->tune_step_walk < 0 && h->bucketing && lpt > 0 && s.reward_fn != D2D_REWARD_CUE_SINR_SHANNON) { lists = 1; s.walk = 2; }
     if (lists && d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) { lists = 0; s.walk = 0; }
     s.lpt = lpt;
     d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, &s.lds);
@@ -467,7 +476,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         s.rb_out = redirect->rb; s.pwr_out = redirect->pwr;        // decoded / fixed values as the kernel used them
         s.sinr_db = redirect->sinr; s.snr_db = redirect->snr; s.rate = redirect->rate; s.cap = redirect->cap;
         s.env_flags = redirect->env_flags;
-        if (s.reward_fn != D2D_REWARD_NONE) s.reward = redirect->reward;
+        if (s.reward_fn != D2D_REWARD_NONE) s.reward = redirect->reward;      // d2d_step_host: always the [B,N] rows
         if (s.write_table) s.table = redirect->table;
         if (h->obs_mode == D2D_OBS_LINEAR) s.obs = redirect->obs;
     } else {
@@ -480,7 +489,8 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         GET(D2D_BUF_RATE_BPS, rate, float*);
         GET(D2D_BUF_CAPACITY, cap, float*);
         GET(D2D_BUF_ENV_FLAGS, env_flags, int*);
-        if (s.reward_fn != D2D_REWARD_NONE) GET(D2D_BUF_REWARD, reward, float*);
+        if (s.reward_fn == D2D_REWARD_SYSTEM_CAPACITY && h->reward_layout == D2D_REWARD_PER_ENV) GET(D2D_BUF_REWARD_ENV, reward_env, float*);
+        else if (s.reward_fn != D2D_REWARD_NONE) GET(D2D_BUF_REWARD, reward, float*);
         if (s.write_table) GET(D2D_BUF_OBS_TABLE, table, float*);
         if (h->obs_mode == D2D_OBS_LINEAR) GET(D2D_BUF_OBS, obs, float*);
     }
@@ -629,7 +639,10 @@ int d2d_destroy(d2d_handle* h) {
     if (!h) return D2D_OK;
     DeviceGuard device_guard_(h->cfg.device_ordinal);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->comm && g_rccl.CommDestroy) {
+        if (h->comm_used) (void)hipDeviceSynchronize();
+        g_rccl.CommDestroy(h->comm);
+    }
     for (auto& ep : h->events) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
     for (auto& bf : h->buf)
         if (bf.ptr && bf.owned) hipFree(bf.ptr);
@@ -707,12 +720,14 @@ int d2d_set_path_loss_shadowing(d2d_handle* h, int32_t n_dev, const double* a_tx
     return D2D_OK;
 }
 
-int d2d_set_path_loss_table(d2d_handle* h, const float* pl_db, int32_t per_env) {
+int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env) {
     if (!h || !pl_db) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     const size_t elems = (size_t)h->D * h->D * (per_env ? (size_t)h->B : 1);
+    // dB -> linear gain in DOUBLE, rounded once: a float32 dB value is off by up to 3.8e-6 dB near 100 dB, which alone is
+    // most of the 1e-5 bar (ABI 2 took floats: worst case 7.3e-6 of the SINR)
     std::vector<float> lin(elems);
-    for (size_t k = 0; k < elems; ++k) lin[k] = (float)std::pow(10.0, -(double)pl_db[k] / 10.0);
+    for (size_t k = 0; k < elems; ++k) lin[k] = (float)std::pow(10.0, -pl_db[k] / 10.0);
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->gain_elems < elems) {
         if (h->gain_table) HIP_TRY(hipFree(h->gain_table));
@@ -785,6 +800,13 @@ int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param) {
     return D2D_OK;
 }
 
+int d2d_set_reward_layout(d2d_handle* h, int32_t layout) {
+    if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    if (layout != D2D_REWARD_PER_AGENT && layout != D2D_REWARD_PER_ENV) return fail(D2D_ERR_INVALID, "unknown reward layout");
+    h->reward_layout = layout;
+    return D2D_OK;
+}
+
 int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
@@ -825,6 +847,10 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
         case D2D_TUNE_OBS_NONTEMPORAL: h->tune_nt = value ? 1 : 0; break;
         case D2D_TUNE_OBS_XCD_REMAP: h->tune_xcd = value < 0 ? 0 : value; break;
         case D2D_TUNE_OBS_VARIANT: h->tune_variant = value; break;
+        case D2D_TUNE_OBS_STAGGER:
+            if (value < 0 || value > 64) return fail(D2D_ERR_INVALID, "stagger must be in [0, 64]");
+            h->tune_stagger = value;
+            break;
         case D2D_TUNE_STEP_THREADS:
             if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(D2D_ERR_INVALID, "threads must be a multiple of 64 in [64,1024]");
             h->tune_step_threads = value;
@@ -887,7 +913,21 @@ int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes) 
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
     if (which == D2D_BUF_OBS && h->N == 0) return fail(D2D_ERR_STATE, "set links before asking for the obs buffer");
-    int rc = ensure_buffer(h, which, dev_ptr);
+    int rc;
+    if (which == D2D_BUF_LINK_POS) {
+        // the rows follow POS_X / POS_Y lazily (refresh_link_positions): bring them up to date for the reader
+        if (!h->have_links || !h->have_pos) return fail(D2D_ERR_STATE, "link positions need d2d_set_links and positions first");
+        rc = refresh_tables(h);
+        if (rc) return rc;
+        void *px = nullptr, *py = nullptr;
+        rc = ensure_buffer(h, D2D_BUF_POS_X, &px);
+        if (rc) return rc;
+        rc = ensure_buffer(h, D2D_BUF_POS_Y, &py);
+        if (rc) return rc;
+        rc = refresh_link_positions(h, static_cast<const float*>(px), static_cast<const float*>(py));
+        if (rc) return rc;
+    }
+    rc = ensure_buffer(h, which, dev_ptr);
     if (rc) return rc;
     if (bytes) *bytes = active_bytes(h, which, h->N ? h->N : h->Nmax);
     return D2D_OK;
@@ -897,6 +937,7 @@ int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
+    if (which == D2D_BUF_LINK_POS) return fail(D2D_ERR_INVALID, "D2D_BUF_LINK_POS is derived from POS_X / POS_Y by the library: read-only");
     Buffer& bf = h->buf[which];
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (bf.ptr && bf.owned) HIP_TRY(hipFree(bf.ptr));
@@ -912,6 +953,7 @@ int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes,
     if (!h || !host_src) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
+    if (which == D2D_BUF_LINK_POS) return fail(D2D_ERR_INVALID, "D2D_BUF_LINK_POS is derived from POS_X / POS_Y by the library: read-only");
     void* p = nullptr;
     int rc = ensure_buffer(h, which, &p);
     if (rc) return rc;
@@ -929,7 +971,13 @@ int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, siz
     if (!h || !host_dst) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
-    const Buffer& bf = h->buf[which];
+    Buffer bf = h->buf[which];
+    if (which == D2D_BUF_LINK_POS) {
+        size_t n = 0;
+        int rc = d2d_get_buffer(h, which, &bf.ptr, &n);
+        if (rc) return rc;
+        bf.bytes = n;
+    }
     if (!bf.ptr) return fail(D2D_ERR_STATE, "buffer has never been written");
     if (src_offset + bytes > bf.bytes) return fail(D2D_ERR_INVALID, "download out of range");
     HIP_TRY(hipMemcpyAsync(host_dst, static_cast<const char*>(bf.ptr) + src_offset, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1085,7 +1133,13 @@ int d2d_comm_init(d2d_handle* h, int32_t world_size, int32_t rank, const void* u
     USE_DEVICE(h);
     int rc = load_rccl();
     if (rc) return rc;
-    if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    if (h->comm) {
+        // a collective of the old communicator may still be in flight on whatever stream the caller gave d2d_allgather (a side
+        // stream that may be gone by now): drain the device, a rare call can afford it
+        if (h->comm_used) HIP_TRY(hipDeviceSynchronize()); else HIP_TRY(hipStreamSynchronize(h->stream));
+        g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr; h->comm_used = false;
+    }
     Id128 id;
     std::memcpy(id.bytes, unique_id, sizeof(id.bytes));
     const int e = g_rccl.CommInitRank(&h->comm, world_size, id, rank);
@@ -1098,9 +1152,9 @@ int d2d_comm_destroy(d2d_handle* h) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (h->comm) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->comm_used) HIP_TRY(hipDeviceSynchronize()); else HIP_TRY(hipStreamSynchronize(h->stream));
         g_rccl.CommDestroy(h->comm);
-        h->comm = nullptr;
+        h->comm = nullptr; h->comm_used = false;
     }
     return D2D_OK;
 }
@@ -1110,6 +1164,7 @@ int d2d_allgather(d2d_handle* h, const void* send_dev, void* recv_dev, size_t by
     if (!h->comm) return fail(D2D_ERR_STATE, "d2d_comm_init has not been called");
     USE_DEVICE(h);
     hipStream_t stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->stream;
+    h->comm_used = true;
     const int e = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, /* ncclInt8 */ 0, h->comm, stream);
     return e ? rccl_fail("ncclAllGather", e) : D2D_OK;
 }
@@ -1156,6 +1211,32 @@ int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double
     return d2d_probe_write_variants(h, bytes, iters, gb_per_s, nullptr, 0);
 }
 
+namespace {
+// one variant of the fill family over `dst`: GB/s sustained over `iters` launches behind one warm-up launch
+int time_fill(d2d_handle* h, float* dst, size_t bytes, const float* src, int variant, int stagger, int iters, hipEvent_t e0, hipEvent_t e1,
+              double* rate) {
+    const int variants = d2d::fill_variants();
+    size_t written = bytes / 16;
+    for (int k = -1; k < iters; ++k) {                     // k == -1: warm-up / page touch
+        if (k == 0) HIP_TRY(hipEventRecord(e0, h->stream));
+        if (variant < 0) HIP_TRY(hipMemsetAsync(dst, k & 0xFF, written * 16, h->stream));     // the runtime's own fill
+        else HIP_TRY(d2d::launch_fill(dst, bytes / 16, (float)k, h->stream, variant, &written, src, stagger));
+        if (variant < 0 && k == -1) {                      // same byte count as the family's variant 0 writes
+            size_t w0 = 0;
+            HIP_TRY(d2d::launch_fill(dst, bytes / 16, 0.0f, h->stream, 0, &w0));
+            written = w0;
+        }
+    }
+    (void)variants;
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *rate = (double)(written * 16) * iters / (ms * 1e-3) / 1e9;
+    return D2D_OK;
+}
+}  // namespace
+
 int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s, double* per_variant, int32_t n) {
     if (!h || !best_gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
     if (n < 0 || (n > 0 && !per_variant)) return fail(D2D_ERR_INVALID, "bad argument");
@@ -1169,25 +1250,42 @@ int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double*
     HIP_TRY(hipEventCreate(&e1));
     const int variants = d2d::fill_variants();
     double best = 0.0;
-    for (int v = 0; v <= variants; ++v) {                      // v == variants: the runtime's own fill (hipMemsetAsync)
-        size_t written = bytes / 16;
-        for (int k = -1; k < iters; ++k) {                     // k == -1: warm-up / page touch
-            if (k == 0) HIP_TRY(hipEventRecord(e0, h->stream));
-            if (v < variants) HIP_TRY(d2d::launch_fill(tmp, bytes / 16, (float)k, h->stream, v, &written));
-            else HIP_TRY(hipMemsetAsync(tmp, k & 0xFF, written * 16, h->stream));
-        }
-        HIP_TRY(hipEventRecord(e1, h->stream));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        const double rate = (double)(written * 16) * iters / (ms * 1e-3) / 1e9;
+    int rc = D2D_OK;
+    for (int v = 0; v <= variants && rc == D2D_OK; ++v) {      // v == variants: the runtime's own fill (hipMemsetAsync)
+        double rate = 0.0;
+        rc = time_fill(h, tmp, bytes, nullptr, v < variants ? v : -1, 0, iters, e0, e1, &rate);
         if (v < n) per_variant[v] = rate;
         if (rate > best) best = rate;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    HIP_TRY(hipFree(tmp));
+    hipFree(tmp);
+    if (rc) return rc;
     *best_gb_per_s = best;
     return D2D_OK;
+}
+
+int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters, double* gb_per_s) {
+    if (!h || !gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
+    if (variant < 0 || variant >= 4 * d2d::fill_variants()) return fail(D2D_ERR_INVALID, "variant must be in [0, 128)");
+    if (stagger < 0 || stagger > 64) return fail(D2D_ERR_INVALID, "stagger must be in [0, 64]");
+    const size_t group = (size_t)8 * 512 * 1024 * 16;
+    if (bytes < group) return fail(D2D_ERR_INVALID, "the probe needs at least 64 MiB");
+    USE_DEVICE(h);
+    float* tmp = static_cast<float*>(dst_dev);
+    if (!dst_dev) HIP_TRY(hipMalloc(&tmp, bytes));
+    // the staged forms read one 1024-float4 row per region of 512 rows: a table 1 / 512 of the destination, as in the obs kernel
+    float* src = nullptr;
+    const size_t src_bytes = bytes / 512 + (size_t)1024 * 16;
+    HIP_TRY(hipMalloc(&src, src_bytes));
+    HIP_TRY(hipMemsetAsync(src, 0, src_bytes, h->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int rc = time_fill(h, tmp, bytes, src, variant, stagger, iters, e0, e1, gb_per_s);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(src);
+    if (!dst_dev) hipFree(tmp);
+    return rc;
 }
 
 }  // extern "C"

@@ -88,6 +88,7 @@ struct StepArgs {
     float* rate;
     float* cap;
     float* reward;           // [B,N] (nullable when reward_fn == 0)
+    float* reward_env;       // [B] SystemCapacity's one scalar per env (D2D_REWARD_PER_ENV); null = the [B,N] row above
     float* table;            // [B,N,6]
     float* obs;              // [B,N,6N] (fuse_obs only)
     int* env_flags;          // [B]  (OR-reduced on demand by launch_flags_or)
@@ -104,13 +105,15 @@ struct ObsArgs {
     int nontemporal;
     int block;               // threads per workgroup (0 -> 256)
     int variant;             // 0: T staged in LDS   1: T read straight from global (A/B)
+    int stagger;             // > 0: wave w of a workgroup sleeps w * stagger x 64 clocks before its stores (A/B)
     const float* table;      // [B,N,6]
     float* obs;              // [B,N,6N]
 };
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
-hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written);
+hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written,
+                       const float* src = nullptr, int stagger = 0);
 int fill_variants();
 size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists);
 void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out);

@@ -58,6 +58,10 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     const unsigned q_per_row = a.q_per_row;
     const unsigned total = (r1 - r0) * q_per_row;
     float* out = a.obs + ((size_t)env * N + r0) * row_floats;   // contiguous slab of rows [r0, r1)
+    if (a.stagger > 0) {                                        // D2D_TUNE_OBS_STAGGER (A/B): wave w waits w * stagger x 64 clocks
+        const int n = (int)(tid >> 6) * a.stagger;
+        for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);
+    }
 
     if (VEC == 4 && q_per_row == T) {
         // The default geometry: one thread per float4 column (block == 6N / 4), so q = tid for every row of the slab and
@@ -155,8 +159,14 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
 // of store geometries that contains the obs kernel's own (one thread per float4 column of a 6N-float row: 768 threads at
 // N = 512, two rows per workgroup, XCD-grouped dispatch order, nontemporal 16-byte stores).  The best of the family (and
 // of the runtime's own hipMemsetAsync) is the box's write ceiling as far as this library can demonstrate one.
-template <bool NT>
-__global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, unsigned chunks, unsigned rows_per_wg, unsigned rows_per_env, int xcd, float value) {
+// STAGE reproduces the obs kernel's TIMING structure around the same stores: bit 0 - every workgroup first stages one row
+// (T float4, 12 KiB at 768 threads) from `src` into LDS behind a barrier and stores what it reads back from LDS; bit 1 - wave w of
+// the workgroup sleeps w * stagger x 64 clocks before its first store.  (Does the obs kernel out-write its own geometry run as
+// a plain fill - 7.19 vs 6.39 TB/s in round 3 - because its load + barrier phase spreads the waves' stores in time?)
+template <bool NT, int STAGE>
+__global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, const f32x4* src, unsigned chunks, unsigned rows_per_wg, unsigned rows_per_env, int xcd,
+                                                    float value, int stagger) {
+    extern __shared__ __align__(16) float fill_lds[];
     unsigned env, chunk;
     if (xcd) {
         const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
@@ -165,7 +175,17 @@ __global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, unsigned chunks,
         env = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
     }
     const unsigned T = blockDim.x;                             // float4 per row
-    const f32x4 v = {value, value, value, value};
+    f32x4 v = {value, value, value, value};
+    if (STAGE & 1) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(fill_lds);
+        l4[threadIdx.x] = src[(size_t)env * T + threadIdx.x];
+        __syncthreads();
+        v = l4[(threadIdx.x + 1u) % T];
+    }
+    if (STAGE & 2) {
+        const int n = (int)(threadIdx.x >> 6) * stagger;
+        for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);
+    }
     f32x4* o4 = dst + ((size_t)env * rows_per_env + (size_t)chunk * rows_per_wg) * T + threadIdx.x;
 #pragma unroll 2
     for (unsigned i = 0; i < rows_per_wg; ++i) {
@@ -174,21 +194,31 @@ __global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, unsigned chunks,
 }
 
 // Variant v of the family: block in {768, 1024, 512, 256} x rows per workgroup in {2, 4, 8, 32} x {nt, plain}, XCD-grouped
-// order; v == 0 is the obs kernel's geometry.  "Envs" are regions of 512 rows; n_float4 is rounded DOWN to whole groups of
-// 8 regions; returns the float4 actually written through *written.
+// order; v == 0 is the obs kernel's geometry.  Bits 5-6 select the staged forms above (32: LDS stage + barrier, 64: per-wave
+// sleep stagger of `stagger` x 64 clocks, 96: both).  "Envs" are regions of 512 rows; n_float4 is rounded DOWN to whole
+// groups of 8 regions; returns the float4 actually written through *written.
 int fill_variants() { return 4 * 4 * 2; }
 
-hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written) {
+hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written, const float* src, int stagger) {
     static const unsigned blocks[4] = {768, 1024, 512, 256}, rows[4] = {2, 4, 8, 32};
     const unsigned T = blocks[variant & 3], rows_per_wg = rows[(variant >> 2) & 3], rows_per_env = 512, chunks = rows_per_env / rows_per_wg;
     const bool nt = ((variant >> 4) & 1) == 0;
+    const int stage = (variant >> 5) & 3;
     const size_t env_f4 = (size_t)rows_per_env * T;
     const size_t envs = (n_float4 / env_f4) & ~(size_t)7;
     if (written) *written = envs * env_f4;
     if (envs == 0) return hipSuccess;
+    if ((stage & 1) && !src) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(envs * chunks)), block(T);
-    if (nt) hipLaunchKernelGGL(fill_kernel<true>, grid, block, 0, stream, reinterpret_cast<f32x4*>(dst), chunks, rows_per_wg, rows_per_env, 1, value);
-    else hipLaunchKernelGGL(fill_kernel<false>, grid, block, 0, stream, reinterpret_cast<f32x4*>(dst), chunks, rows_per_wg, rows_per_env, 1, value);
+    const size_t lds = (stage & 1) ? (size_t)T * 16 : 0;
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+#define D2D_FILL(NTV, ST) hipLaunchKernelGGL((fill_kernel<NTV, ST>), grid, block, lds, stream, d4, s4, chunks, rows_per_wg, rows_per_env, 1, value, stagger)
+    switch ((nt ? 4 : 0) | stage) {
+        case 0: D2D_FILL(false, 0); break; case 1: D2D_FILL(false, 1); break; case 2: D2D_FILL(false, 2); break; case 3: D2D_FILL(false, 3); break;
+        case 4: D2D_FILL(true, 0); break; case 5: D2D_FILL(true, 1); break; case 6: D2D_FILL(true, 2); break; default: D2D_FILL(true, 3); break;
+    }
+#undef D2D_FILL
     return hipGetLastError();
 }
 

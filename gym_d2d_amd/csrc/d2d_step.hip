@@ -96,7 +96,9 @@ __device__ __forceinline__ float pow_neg_half(float d2, float2 h) {
 #pragma clang fp contract(off)
     const float m = __builtin_amdgcn_frexp_mantf(d2);       // [0.5, 1)
     const float fe = (float)__builtin_amdgcn_frexp_expf(d2);
-    const float l = __builtin_amdgcn_logf(m);               // v_log_f32 = log2, in [-1, 0)
+    // v_log_f32 = log2, in [-1, 0); log2(0) = -inf is held at -1e30 so that the tail product below stays finite and d2 == 0
+    // still ends in exp2(+huge) = +inf (0 * -inf or +x * -inf in the tail made it NaN, unlike the 1 / d^2 mode)
+    const float l = fmaxf(__builtin_amdgcn_logf(m), -1.0e30f);
     const float p = h.x * fe;                               // exact: 12 bits x at most 8
     const float ip = rintf(p);
     const float fr = (p - ip) + fmaf(h.x, l, h.y * (l + fe));
@@ -900,8 +902,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const int viol = atomicOr(&s.flags[1], 0);
                 const float r = (viol & 1) ? -1.0f : ((viol & 4) ? __int_as_float(0x7FC00000) : ((viol & 2) ? __int_as_float(0x7F800000) : total * a.inv_n));
                 // N = LPT * blockDim is a multiple of 64: the row goes out as 16-byte stores
-                const f32x4 r4 = {r, r, r, r};
-                for (int k = lane * 4; k < N; k += 256) ST(reinterpret_cast<f32x4*>(at(a.reward, fresh((row + (unsigned)k) * 4u))), r4);
+                if (a.reward_env) {                                            // D2D_REWARD_PER_ENV: the scalar once, not N copies
+                    if (lane == 0) a.reward_env[b] = r;
+                } else {
+                    const f32x4 r4 = {r, r, r, r};
+                    for (int k = lane * 4; k < N; k += 256) ST(reinterpret_cast<f32x4*>(at(a.reward, fresh((row + (unsigned)k) * 4u))), r4);
+                }
             }
             if (lane == 0) a.env_flags[b] = atomicOr(&s.flags[0], 0);
         }
@@ -920,7 +926,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             float total = 0.0f;
             for (int w = 0; w < (TPE + 255) >> 8; ++w) { const float4 v = red4[w]; total += (v.x + v.y) + (v.z + v.w); }
             const float r = s.flags[1] ? -1.0f : total * a.inv_n;
-            FOR_MY_LINKS(u, i) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = r;
+            if (a.reward_env) { if (lt == 0) a.reward_env[b] = r; }
+            else { FOR_MY_LINKS(u, i) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = r; }
         }
     } else if (cfg_reward_fn == 2) {
         // ShannonRewardFunction, reward_fn.py:52-57

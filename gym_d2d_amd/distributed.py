@@ -15,6 +15,11 @@ Against the compact-obs step (about 30 us at 4096 x 512) even those 16.8 MB are 
 then gathers rewards only (mode='rewards', 16 KB per GPU) and / or ships the (sinr, snr) columns on every K-th step
 (signal_every=K).
 
+mode='planes' is the same plan for a learner whose ranks run D2D_OBS_NONE (no table is written at all, 24 of the compact
+step's 64 bytes per link): the per-step gather takes the (sinr_dB, snr_dB) result PLANES [B_local, N] themselves - two
+contiguous sends, no strided slice out of a table - and the positions come once per reset from the library's link rows
+(D2D_BUF_LINK_POS [B_local, N, 4]); `table()` assembles the same [B_global, N, 6] on the consumer, bit for bit.
+
 The per-step gather runs on a side stream from a staging copy, so it overlaps the obs-expansion kernel and the next
 step; only the small device-to-device staging copy is ordered against the next step's writes.
 Backend "nccl" is RCCL on ROCm; "gloo" works for CPU tensors (used by the CPU tests).
@@ -40,8 +45,9 @@ class StepGatherer:
     """All-gather of per-step results across ranks with equal shard sizes.
 
         g = StepGatherer(b_local, n_links, device)
-        g.gather_positions(table)              # after every reset: the 4 position columns, synchronous
+        g.gather_positions(table)              # after every reset: the 4 position columns ([B,N,6] table or [B,N,4] link rows)
         g.launch(reward, table)                # after every step: rewards (+ (sinr, snr)), asynchronous
+        g.launch(reward, sinr=s, snr=n)        # mode 'planes': the two result planes instead of the table
         rewards, signal = g.wait()             # [B_global], [B_global, N, 2]
         table = g.table()                      # [B_global, N, 6] assembled on demand
 
@@ -49,8 +55,12 @@ class StepGatherer:
     sized against the 3.7 ms LinearObs step).  mode 'rewards': rewards only - B_local floats, 16 KB per GPU - for the
     compact-obs step (32 us at 4096 x 512), which a 16.8 MB ring all-gather (>= 0.3 ms over one ~100 GB/s xGMI link per
     hop) would outlast ten times over; the learner then reads observations through `signal_every`.
+    mode 'planes': as 'table', but the per-step payload is read from the step's own sinr_db / snr_db planes (launch(reward,
+    sinr=..., snr=...)) - for ranks that run D2D_OBS_NONE; rewards may be the per-env vector [B_local] (D2D_REWARD_PER_ENV).
     signal_every = K > 1: the (sinr, snr) columns ride along on every K-th launch only (the first included); `wait()` keeps
     returning the last gathered signal and `signal_step` says which launch it belongs to.
+    With reward_every > 1 call `flush()` at the end of a rollout whose length is not a multiple of K: it gathers the partly
+    filled ring and returns how many of its rows are valid.
     reward_every = K > 1 (mode 'rewards'): the host cost of ONE gather launch (stream hand-over, staging copy, collective: about 35 us
     through torch.distributed, measured with one rank) is more than a whole compact-obs step (about 28 us at 4096 x 512), so a
     per-step gather makes the step loop host bound.  With K > 1 every launch only copies the step's rewards into slot
@@ -85,8 +95,8 @@ class StepGatherer:
                              'pad the batch to a multiple of the world size')
         if backend not in ('torch', 'native'):
             raise ValueError("backend must be 'torch' or 'native'")
-        if mode not in ('table', 'rewards'):
-            raise ValueError("mode must be 'table' or 'rewards'")
+        if mode not in ('table', 'rewards', 'planes'):
+            raise ValueError("mode must be 'table', 'rewards' or 'planes'")
         if signal_every < 1:
             raise ValueError('signal_every must be >= 1')
         if reward_every < 1 or (reward_every > 1 and (mode != 'rewards' or per_agent_reward)):
@@ -117,11 +127,16 @@ class StepGatherer:
         if mode == 'table':
             self.stage_signal = torch.empty((b_local, n_links, 2), dtype=f32, device=device)
             self.all_signal = torch.zeros((self.world * b_local, n_links, 2), dtype=f32, device=device)
+        self.stage_planes = self.all_planes = None
+        if mode == 'planes':                    # [0] sinr_dB, [1] snr_dB: each plane contiguous on both sides of the collective
+            self.stage_planes = [torch.empty((b_local, n_links), dtype=f32, device=device) for _ in range(2)]
+            self.all_planes = [torch.zeros((self.world * b_local, n_links), dtype=f32, device=device) for _ in range(2)]
         self.all_positions = torch.zeros((self.world * b_local, n_links, 4), dtype=f32, device=device)
         self.launches = 0
+        self._ring_pos = 0                      # ring slots consumed (launches + the slots a flush() skipped)
         self.signal_step = -1                   # index of the launch the gathered signal belongs to
         self.bytes_per_launch = self.stage_reward.numel() * 4       # per step (reward_every > 1: K of them travel together)
-        self.bytes_per_signal_launch = self.bytes_per_launch + (self.stage_signal.numel() * 4 if mode == 'table' else 0)
+        self.bytes_per_signal_launch = self.bytes_per_launch + (b_local * n_links * 8 if mode in ('table', 'planes') else 0)
         self._timing = bool(timing) and self.cuda
         self._events = []
         self._launch_mark = 0
@@ -138,8 +153,11 @@ class StepGatherer:
             dist.all_gather_into_tensor(out, local, group=self.group)
 
     def gather_positions(self, table: torch.Tensor) -> torch.Tensor:
-        """Once per episode: all ranks' (tx_x, tx_y, rx_x, rx_y) columns of T -> [B_global, N, 4].  Ordered after the
-        work already enqueued on the current stream and before whatever the caller enqueues next."""
+        """Once per episode: all ranks' (tx_x, tx_y, rx_x, rx_y) columns of T -> [B_global, N, 4].  `table` is the obs table
+        [B_local, N, 6] or the link-position rows [B_local, N, 4] themselves (D2D_BUF_LINK_POS: mode 'planes', where no table
+        exists).  Ordered after the work already enqueued on the current stream and before whatever the caller enqueues next."""
+        if table.shape[-1] not in (4, 6):
+            raise ValueError('gather_positions takes the [B, N, 6] obs table or the [B, N, 4] link-position rows')
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)
             self.comm_stream.wait_stream(cur)                   # the reset's rows are ready; earlier gathers precede us there
@@ -152,15 +170,25 @@ class StepGatherer:
             self._all_gather(self.all_positions, table[:, :, :4].contiguous())
         return self.all_positions
 
-    def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor = None) -> None:
+    def launch(self, reward_per_agent: torch.Tensor, table: torch.Tensor = None, *, sinr: torch.Tensor = None,
+               snr: torch.Tensor = None) -> None:
         """Call right after the step was enqueued on the current stream.  reward_per_agent [B_local, N] (column 0
-        is the env's scalar for SystemCapacity), table [B_local, N, 6] (mode 'table')."""
+        is the env's scalar for SystemCapacity) or the per-env vector [B_local] (D2D_REWARD_PER_ENV); table [B_local, N, 6]
+        (mode 'table'); sinr / snr [B_local, N] (mode 'planes')."""
         if self.reward_every > 1:
             return self._launch_ring(reward_per_agent)
-        with_signal = self.mode == 'table' and self.launches % self.signal_every == 0
-        if with_signal and table is None:
+        with_signal = self.mode in ('table', 'planes') and self.launches % self.signal_every == 0
+        if with_signal and self.mode == 'table' and table is None:
             raise ValueError("mode 'table' gathers the (sinr, snr) columns: pass the obs table")
-        src_reward = reward_per_agent if self.per_agent_reward else reward_per_agent[:, 0]
+        planes = self.mode == 'planes'
+        if with_signal and planes and (sinr is None or snr is None):
+            raise ValueError("mode 'planes' gathers the sinr_db / snr_db planes: pass sinr= and snr=")
+        if reward_per_agent.dim() == 1:
+            if self.per_agent_reward:
+                raise ValueError('per_agent_reward needs the [B, N] reward rows')
+            src_reward = reward_per_agent
+        else:
+            src_reward = reward_per_agent if self.per_agent_reward else reward_per_agent[:, 0]
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)
             self.comm_stream.wait_stream(cur)                   # results of this step are ready
@@ -168,21 +196,30 @@ class StepGatherer:
                 if self._timing:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record(self.comm_stream)
                 self.stage_reward.copy_(src_reward)
-                if with_signal:
+                if with_signal and planes:
+                    self.stage_planes[0].copy_(sinr); self.stage_planes[1].copy_(snr)      # contiguous: plain block copies
+                elif with_signal:
                     self.stage_signal.copy_(table[:, :, 4:6])
                 self.staged.record(self.comm_stream)
                 self._all_gather(self.all_reward, self.stage_reward, self.comm_stream.cuda_stream)
-                if with_signal:
+                if with_signal and planes:
+                    for k in range(2):
+                        self._all_gather(self.all_planes[k], self.stage_planes[k], self.comm_stream.cuda_stream)
+                elif with_signal:
                     self._all_gather(self.all_signal, self.stage_signal, self.comm_stream.cuda_stream)
                 self.done.record(self.comm_stream)
                 if self._timing:
                     e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
-                    self._events.append((e0, e1))
+                    self._record(e0, e1)
             cur.wait_event(self.staged)                         # next step may overwrite table/reward now
         else:
             self.stage_reward.copy_(src_reward)
             self._all_gather(self.all_reward, self.stage_reward)
-            if with_signal:
+            if with_signal and planes:
+                for k, src in enumerate((sinr, snr)):
+                    self.stage_planes[k].copy_(src)
+                    self._all_gather(self.all_planes[k], self.stage_planes[k])
+            elif with_signal:
                 self.stage_signal.copy_(table[:, :, 4:6])
                 self._all_gather(self.all_signal, self.stage_signal)
         if with_signal:
@@ -192,37 +229,65 @@ class StepGatherer:
 
     def _launch_ring(self, reward_per_agent: torch.Tensor) -> None:
         k = self.reward_every
-        slot, which = self.launches % k, (self.launches // k) % 2
+        slot, which = self._ring_pos % k, (self._ring_pos // k) % 2
         ring = self.rings[which]
+        src = reward_per_agent if reward_per_agent.dim() == 1 else reward_per_agent[:, 0]
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)
             if slot == 0 and self._ring_free[which] is not None:
                 cur.wait_event(self._ring_free[which])          # the gather that read this ring two blocks ago is done (long since)
-            ring[slot].copy_(reward_per_agent[:, 0])            # on the current stream: ordered with the step, no hand-over
-            if slot == k - 1:
-                self.comm_stream.wait_stream(cur)
-                with torch.cuda.stream(self.comm_stream):
-                    if self._timing:
-                        e0 = torch.cuda.Event(enable_timing=True); e0.record(self.comm_stream)
-                    self._all_gather(self.all_ring.view(-1), ring.view(-1), self.comm_stream.cuda_stream)
-                    self.done.record(self.comm_stream)
-                    free = torch.cuda.Event(); free.record(self.comm_stream)
-                    self._ring_free[which] = free
-                    if self._timing:
-                        e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
-                        self._events.append((e0, e1))
-                self.reward_step = self.launches - (k - 1)
-                self._pending = True
+            ring[slot].copy_(src)                               # on the current stream: ordered with the step, no hand-over
         else:
-            ring[slot].copy_(reward_per_agent[:, 0])
-            if slot == k - 1:
-                self._all_gather(self.all_ring.view(-1), ring.view(-1))
-                self.reward_step = self.launches - (k - 1)
-                self._pending = True
+            ring[slot].copy_(src)
+        if slot == k - 1:
+            self._gather_ring(which, self.launches - (k - 1))
         self.launches += 1
+        self._ring_pos += 1
+
+    def _gather_ring(self, which: int, first_step: int) -> None:
+        ring = self.rings[which]
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                if self._timing:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(self.comm_stream)
+                self._all_gather(self.all_ring.view(-1), ring.view(-1), self.comm_stream.cuda_stream)
+                self.done.record(self.comm_stream)
+                free = torch.cuda.Event(); free.record(self.comm_stream)
+                self._ring_free[which] = free
+                if self._timing:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
+                    self._record(e0, e1)
+        else:
+            self._all_gather(self.all_ring.view(-1), ring.view(-1))
+        self.reward_step = first_step
+        self._pending = True
+
+    def flush(self) -> int:
+        """reward_every > 1: gather the ring as it stands when the rollout did not end on a block boundary (launches % K != 0).
+        Returns how many leading rows of the [K, B_global] block `wait()` then returns are valid (rows = launches
+        `reward_step` ... `reward_step` + valid - 1; the rest of the block is older data); 0 = nothing was pending.
+        Every rank must call it (it is a collective).  The next launch starts a new block."""
+        k = self.reward_every
+        valid = self._ring_pos % k if k > 1 else 0
+        if valid == 0:
+            return 0
+        self._gather_ring((self._ring_pos // k) % 2, self.launches - valid)
+        self._ring_pos += k - valid                             # the next launch opens the next block (slot 0, the other ring)
+        return valid
+
+    def _record(self, e0, e1) -> None:
+        self._events.append((e0, e1))
+        if len(self._events) > 8192:                            # long timed runs: fold the older half into a running sum
+            drop = len(self._events) // 2
+            self._events[drop - 1][1].synchronize()
+            self._dropped_ms = getattr(self, '_dropped_ms', 0.0) + sum(a.elapsed_time(b) for a, b in self._events[:drop])
+            del self._events[:drop]
 
     def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(rewards [B_global] (or [B_global, N]), signal [B_global, N, 2] = sinr_dB, snr_dB - None in mode 'rewards') of
+        """(rewards [B_global] (or [B_global, N]), signal [B_global, N, 2] = sinr_dB, snr_dB - None in mode 'rewards'; in
+        mode 'planes' the pair of planes (sinr_dB, snr_dB), each [B_global, N]) of
         the last launched gather, rank-major = global env order.  With signal_every > 1 the signal is that of launch
         `signal_step`."""
         if self.cuda and self._pending:
@@ -231,6 +296,8 @@ class StepGatherer:
         if self.reward_every > 1:
             # [world, K, b_local] -> [K, B_global]: rank-major along the env axis = global env order
             return self.all_ring.permute(1, 0, 2).reshape(self.reward_every, -1), None
+        if self.mode == 'planes':
+            return self.all_reward, tuple(self.all_planes)      # (sinr_dB [B_global, N], snr_dB [B_global, N])
         return self.all_reward, self.all_signal
 
     def table(self) -> torch.Tensor:
@@ -238,6 +305,8 @@ class StepGatherer:
         _, signal = self.wait()
         if signal is None:
             raise ValueError("mode 'rewards' gathers no observation columns")
+        if self.mode == 'planes':
+            return torch.cat([self.all_positions, signal[0].unsqueeze(2), signal[1].unsqueeze(2)], dim=2)
         return torch.cat([self.all_positions, signal], dim=2)
 
     def gather_ms(self) -> float:
@@ -247,12 +316,13 @@ class StepGatherer:
             return 0.0
         self._events[-1][1].synchronize()
         launches = max(1, self.launches - self._launch_mark)      # reward_every > 1: one gather per K launches
-        return sum(e0.elapsed_time(e1) for e0, e1 in self._events) / launches
+        return (getattr(self, '_dropped_ms', 0.0) + sum(e0.elapsed_time(e1) for e0, e1 in self._events)) / launches
 
     def reset_timing(self) -> None:
         if self._events:
             self._events[-1][1].synchronize()
         self._events = []
+        self._dropped_ms = 0.0
         self._launch_mark = self.launches
 
 

@@ -72,3 +72,18 @@ class OwnLinkObsFunction(ArrayObsFunction):
 
     def compute(self, view):
         return view.table
+
+
+class SignalPlanesObsFunction(ArrayObsFunction):
+    """No observation array is materialised at all (D2D_OBS_NONE: the step writes neither the [B,N,6N] block nor the
+    compact [B,N,6] table): a learner that builds its own features reads the step's (sinr_dB, snr_dB) planes - the only
+    columns of the table that change within an episode (obs_fn.py:57-60) - and takes the four position columns once per
+    reset from `VecD2DEnv.link_positions()` ([B,N,4], simulator.py:61-75 only moves devices in reset()).  compute()
+    returns the pair of planes; `distributed.StepGatherer(mode='planes')` ships exactly these across GPUs."""
+    native_mode = _native.OBS_NONE
+
+    def get_obs_space(self, env_config) -> Space:
+        return Box(low=-np.inf, high=np.inf, shape=(2,))
+
+    def compute(self, view):
+        return view.sinr_db, view.snr_db

@@ -39,7 +39,7 @@ _OUTPUTS = (('sinr_db', _native.BUF_SINR_DB), ('snr_db', _native.BUF_SNR_DB), ('
 class VecD2DEnv:
     def __init__(self, env_config: Optional[dict] = None, num_envs: Optional[int] = None, *,
                  cue_actions: str = 'agent', use_torch: Optional[bool] = None, first_env: int = 0,
-                 export_actions: bool = True) -> None:
+                 export_actions: bool = True, reward_per_env: bool = False) -> None:
         """cue_actions: 'agent' - step() takes actions for CUEs and DUEs [B, C+P] (reference behaviour);
         'traffic' - CUE links follow the env's traffic model (round-robin RB at max power,
         traffic_model.py:15-22): their (rb, pwr) are constants of the kernel's link records
@@ -51,6 +51,13 @@ class VecD2DEnv:
         export_actions: False - the kernel does not write the decoded (rb, tx power) planes behind info['rb'] /
         info['tx_pwr_dbm'] (d2d_set_export_actions: 8 of the step's 72 bytes per link; a rollout knows its own actions);
         the two info entries are then None.
+
+        reward_per_env: True - SystemCapacityRewardFunction's reward is ONE scalar per env handed to every agent
+        (reward_fn.py:42-44); step() then returns it as [B] instead of N copies [B, N] (d2d_set_reward_layout: 4 bytes per
+        link and step less).  Only with the native SystemCapacity reward.
+
+        step()'s `dones` on the torch path is one of two preallocated CONSTANT tensors (all False / all True), shared by
+        every call: treat it as read-only (clone it before an in-place update).
 
         env_config['obs_dtype'] = 'float64' returns observations in the reference's dtype (obs_fn.py:51 builds float64
         arrays); the default float32 is the kernels' own block, zero copy.
@@ -108,6 +115,11 @@ class VecD2DEnv:
         h.set_obs_mode(self.obs_fn.native_mode)
         h.set_reward(rid, float(getattr(self.reward_fn, 'native_param', 0.0)))
         self._native_reward = bool(rid)
+        self.reward_per_env = bool(reward_per_env)
+        if self.reward_per_env:
+            if rid != _native.REWARD_SYSTEM_CAPACITY:
+                raise ValueError('reward_per_env needs the native SystemCapacityRewardFunction (the per-agent rewards differ per link)')
+            h.set_reward_layout(_native.REWARD_PER_ENV)
         self._array_obs = isinstance(self.obs_fn, ArrayObsFunction)
         self.use_torch = (torch is not None and torch.cuda.is_available()) if use_torch is None else use_torch
         self._t = {}
@@ -137,8 +149,14 @@ class VecD2DEnv:
         for name, which in (('rb', _native.BUF_RB), ('pwr', _native.BUF_PWR)):
             self._t[name] = alloc(which, (b * cap,), torch.int32)[:b * n].view(b, n)
         for name, which in _OUTPUTS:
+            if name == 'reward' and self.reward_per_env:
+                self._t[name] = alloc(_native.BUF_REWARD_ENV, (b,), torch.float32)
+                continue
             self._t[name] = alloc(which, (b * cap,), torch.float32)[:b * n].view(b, n)
-        self._t['table'] = alloc(_native.BUF_OBS_TABLE, (b * cap * 6,), torch.float32)[:b * n * 6].view(b, n, 6)
+        if self.obs_fn.native_mode != _native.OBS_NONE:
+            self._t['table'] = alloc(_native.BUF_OBS_TABLE, (b * cap * 6,), torch.float32)[:b * n * 6].view(b, n, 6)
+        else:
+            self._t['table'] = None                        # D2D_OBS_NONE: no table exists; positions: link_positions()
         self._t['env_flags'] = alloc(_native.BUF_ENV_FLAGS, (b,), torch.int32)
         if self.obs_fn.native_mode == _native.OBS_LINEAR:
             self._t['obs'] = alloc(_native.BUF_OBS, (b, n, 6 * n), torch.float32)
@@ -169,10 +187,11 @@ class VecD2DEnv:
                 return self._view_cache
             v = dict(self._t)
         else:
-            v = {name: sim.fetch(which) for name, which in _OUTPUTS if name != 'reward' or
-                 getattr(self.reward_fn, 'native_id', 0)}
-            v['rb'] = sim.fetch(_native.BUF_RB); v['pwr'] = sim.fetch(_native.BUF_PWR)
-            v['table'] = sim.fetch(_native.BUF_OBS_TABLE)
+            v = {name: sim.fetch(_native.BUF_REWARD_ENV if name == 'reward' and self.reward_per_env else which)
+                 for name, which in _OUTPUTS if name != 'reward' or getattr(self.reward_fn, 'native_id', 0)}
+            if self.export_actions:                        # otherwise the two planes are stale / never written
+                v['rb'] = sim.fetch(_native.BUF_RB); v['pwr'] = sim.fetch(_native.BUF_PWR)
+            v['table'] = sim.fetch(_native.BUF_OBS_TABLE) if self.obs_fn.native_mode != _native.OBS_NONE else None
             v['pos_x'] = sim.fetch(_native.BUF_POS_X); v['pos_y'] = sim.fetch(_native.BUF_POS_Y)
             if self.obs_fn.native_mode == _native.OBS_LINEAR:
                 v['obs'] = sim.fetch(_native.BUF_OBS)
@@ -253,6 +272,21 @@ class VecD2DEnv:
         if self._obs64:                                   # the reference's dtype (obs_fn.py:51), on request
             obs = obs.double() if self.use_torch else np.asarray(obs, dtype=np.float64)
         return obs
+
+    def link_positions(self):
+        """[B, N, 4] float32 (tx_x, tx_y, rx_x, rx_y) of every link = columns 0-3 of the obs table (obs_fn.py:57-59), constant
+        between resets.  torch path: a zero-copy view of the library's own rows (D2D_BUF_LINK_POS) - read-only, valid until
+        close(), refreshed by the library on reset."""
+        h = self.simulator.handle
+        if not self.use_torch:
+            return h.download(_native.BUF_LINK_POS)
+        ptr, nbytes = h.get_buffer(_native.BUF_LINK_POS)           # also brings the rows up to date on the current stream
+        if getattr(self, '_lpos_view', None) is None or self._lpos_view[0] != (ptr, nbytes):
+            shape = (self.num_envs, self.num_links, 4)
+            holder = SimpleNamespace(__cuda_array_interface__={'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2,
+                                                              'strides': None})
+            self._lpos_view = ((ptr, nbytes), torch.as_tensor(holder, device=self.device))
+        return self._lpos_view[1]
 
     def action_buffer(self):
         """The bound int32 [B, num_agents] action tensor (step() with no copy also accepts any contiguous int32 CUDA

@@ -39,18 +39,25 @@ class PathLoss(ABC):
         else None (the table route is used)."""
         return None
 
-    def table_db(self, devices: Sequence[Device]) -> np.ndarray:
-        """Host evaluation of every ordered device pair: out[tx_index, rx_index] in dB.  A pair the model cannot
-        evaluate (zero distance -> ValueError in math.log10) is stored as NaN; the env raises if such a pair is
-        ever used, which is when the reference would have raised."""
+    def table_db(self, devices: Sequence[Device], tx_indices: Optional[Sequence[int]] = None,
+                 rx_indices: Optional[Sequence[int]] = None) -> np.ndarray:
+        """Host evaluation of the model: out[tx_index, rx_index] in dB (float64, as the plugin returns it).  Only the pairs
+        (tx in tx_indices) x (rx in rx_indices) are evaluated - the transmitters and receivers of the links that act: the
+        step reads PL(tx of link j, rx of link i) and nothing else (simulator.py:93,100,114), which at 256 CUE + 256 DUE
+        pairs is 512 x 257 calls instead of 769 x 769.  None = every device.  Everything else stays NaN, as does a pair the
+        model cannot evaluate (zero distance -> ValueError in math.log10); the env raises if such a pair is ever used,
+        which is when the reference would have raised."""
         devs = list(devices)
         out = np.full((len(devs), len(devs)), np.nan, dtype=np.float64)
-        for i, tx in enumerate(devs):
-            for j, rx in enumerate(devs):
+        txs = range(len(devs)) if tx_indices is None else sorted(set(int(i) for i in tx_indices))
+        rxs = range(len(devs)) if rx_indices is None else sorted(set(int(j) for j in rx_indices))
+        for i in txs:
+            tx = devs[i]
+            for j in rxs:
                 if i == j:
                     continue
                 try:
-                    out[i, j] = self(tx, rx)
+                    out[i, j] = self(tx, devs[j])
                 except (ValueError, ZeroDivisionError):
                     pass
         return out

@@ -96,6 +96,8 @@ class Simulator:
         self._link_sig = None
         self._episode = 0
         self._table_route = False
+        self._pl_covered = 0                         # 0: no positions yet; None: positions set, table not evaluated
+        self._pl_positions = None
         self._install_tables()
 
     # ------------------------------------------------------------------ lowering of configuration
@@ -118,27 +120,38 @@ class Simulator:
             self._table_route = True    # evaluated per episode in _refresh_path_loss_table()
 
     def _refresh_path_loss_table(self, positions: Optional[np.ndarray] = None) -> None:
-        """Python-plugin route: evaluate the user's PathLoss for every ordered device pair of every env."""
+        """Python-plugin route: evaluate the user's PathLoss for the (transmitter of a link) x (receiver of a link) device
+        pairs of every env - the only entries the step reads; with no link list yet the evaluation waits for set_links."""
         if not self._table_route:
             return
+        self._pl_covered = None                     # positions changed: nothing evaluated for them yet
+        self._pl_positions = positions
+        if self._link_sig:
+            self._evaluate_path_loss_table()
+
+    def _evaluate_path_loss_table(self) -> None:
+        txs, rxs = set(self.link_tx.tolist()), set(self.link_rx.tolist())
+        if self._pl_covered is not None:            # same positions, a changed link list: keep what is already there
+            if txs <= self._pl_covered[0] and rxs <= self._pl_covered[1]:
+                return
+            txs |= self._pl_covered[0]; rxs |= self._pl_covered[1]
         if self.num_envs == 1:
-            self._pl_table = self.path_loss.table_db(self._dev_list)
-            self.handle.set_path_loss_table(self._pl_table)
-            return
-        if positions is None:
-            positions = self.positions()
-        tables = np.empty((self.num_envs, len(self._dev_list), len(self._dev_list)), dtype=np.float32)
-        saved = [d.position for d in self._dev_list]
-        try:
-            for b in range(self.num_envs):
-                for d, xy in zip(self._dev_list, positions[b]):
-                    d.set_position(Position(float(xy[0]), float(xy[1])))
-                tables[b] = self.path_loss.table_db(self._dev_list)
-        finally:
-            for d, p in zip(self._dev_list, saved):
-                d.set_position(p)
-        self._pl_table = tables
-        self.handle.set_path_loss_table(tables)
+            self._pl_table = self.path_loss.table_db(self._dev_list, txs, rxs)
+        else:
+            positions = self._pl_positions if self._pl_positions is not None else self.positions()
+            tables = np.empty((self.num_envs, len(self._dev_list), len(self._dev_list)), dtype=np.float64)
+            saved = [d.position for d in self._dev_list]
+            try:
+                for b in range(self.num_envs):
+                    for d, xy in zip(self._dev_list, positions[b]):
+                        d.set_position(Position(float(xy[0]), float(xy[1])))
+                    tables[b] = self.path_loss.table_db(self._dev_list, txs, rxs)
+            finally:
+                for d, p in zip(self._dev_list, saved):
+                    d.set_position(p)
+            self._pl_table = tables
+        self.handle.set_path_loss_table(self._pl_table)
+        self._pl_covered = (txs, rxs)
 
     def fixed_positions(self):
         """(mask[D] uint8, xy[D,2] float32) of devices pinned by the device_config_file (simulator.py:65-66)."""
@@ -182,6 +195,8 @@ class Simulator:
         self.link_tx = np.asarray(tx, dtype=np.int32)
         self.link_rx = np.asarray(rx, dtype=np.int32)
         self.link_type = np.asarray(types, dtype=np.int32)
+        if self._table_route and getattr(self, '_pl_covered', 0) != 0:
+            self._evaluate_path_loss_table()         # pairs the new link list reads that the table does not hold yet
 
     @property
     def link_keys(self) -> List[Tuple[Id, Id]]:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 2
+#define D2D_ABI_VERSION 3      /* 3: double path-loss tables, per-env reward, link-position rows, staged write probe */
 #define D2D_MAX_LINKS 2048      /* links per env the step kernel's LDS staging is sized for */
 #define D2D_UNIQUE_ID_BYTES 128 /* size of an RCCL unique id (ncclUniqueId)                  */
 
@@ -73,7 +73,14 @@ typedef enum d2d_buffer {
     D2D_BUF_OBS_TABLE = 10, /* f32 [B,N,6]                          (obs_fn.py:55-61)               */
     D2D_BUF_OBS = 11,       /* f32 [B,N,6N]                         (obs_fn.py:43-53)               */
     D2D_BUF_ENV_FLAGS = 12, /* i32 [B]     D2D_FLAG_* bits raised by the last step                  */
-    D2D_BUF_COUNT = 13
+    D2D_BUF_LINK_POS = 13,  /* f32 [B,N,4] (tx_x,tx_y,rx_x,rx_y) of every link = columns 0-3 of the obs
+                               table (obs_fn.py:57-59).  READ-ONLY, library-owned (cannot be bound or
+                               uploaded): derived from POS_X / POS_Y and the link list, constant between
+                               resets (simulator.py:61-75) - a learner that runs D2D_OBS_NONE takes the
+                               positions from here once per episode and (sinr, snr) from the planes     */
+    D2D_BUF_REWARD_ENV = 14,/* f32 [B]     SystemCapacity's one scalar per env (reward_fn.py:42-44),
+                               written instead of D2D_BUF_REWARD under D2D_REWARD_PER_ENV             */
+    D2D_BUF_COUNT = 15
 } d2d_buffer;
 
 #define D2D_FLAG_ZERO_DISTANCE 1u /* an interacting tx/rx pair at distance 0: the reference raises
@@ -137,8 +144,10 @@ int d2d_set_path_loss_shadowing(d2d_handle* h, int32_t n_dev, const double* a_tx
 
 /* PathLoss plugin, table route for arbitrary Python subclasses (path_loss.py:12-25;
  * examples/custom_path_loss.py:8-16): pl_db[(e,) tx_dev, rx_dev] evaluated on the host once per
- * episode.  per_env = 0: one [D,D] table shared by all envs; 1: [B,D,D].                           */
-int d2d_set_path_loss_table(d2d_handle* h, const float* pl_db, int32_t per_env);
+ * episode.  per_env = 0: one [D,D] table shared by all envs; 1: [B,D,D].  float64 dB in (as the plugin
+ * returns them), converted to linear gains in double and rounded once; entries of pairs that no link
+ * uses may hold anything (NaN included) - only (tx of link j, rx of link i) pairs are ever read.       */
+int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env);
 
 /* Which (tx, rx) device pairs act this step and as what (Action.tx/rx/link_type, actions.py:9-15;
  * typing rule d2d_env.py:80-91).  n_links <= max_links.  Order = agent order of the outputs.       */
@@ -160,6 +169,13 @@ int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_id
 /* RewardFunction / ObsFunction plugin selection (d2d_env.py:27-28).                                */
 int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param);
 int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode);
+/* SystemCapacityRewardFunction hands the SAME scalar to every agent of an env (reward_fn.py:42-44).
+ * D2D_REWARD_PER_AGENT (default): d2d_step writes it N times, D2D_BUF_REWARD f32 [B,N] - the dict the
+ * reference returns.  D2D_REWARD_PER_ENV: written once per env to D2D_BUF_REWARD_ENV f32 [B]; D2D_BUF_REWARD
+ * is then not touched (4 bytes per link and step less).  Only SystemCapacity is affected: the per-agent
+ * rewards (Shannon, CueSinrShannon) and d2d_step_host always produce [B,N].                              */
+typedef enum d2d_reward_layout { D2D_REWARD_PER_AGENT = 0, D2D_REWARD_PER_ENV = 1 } d2d_reward_layout;
+int d2d_set_reward_layout(d2d_handle* h, int32_t layout);
 /* 1 (default): same-RB interferers found through per-RB membership bitmasks in LDS
  * (Actions.get_actions_by_rb, actions.py:27-31).  0: masked all-pairs sweep.  Same results.        */
 int d2d_set_bucketing(d2d_handle* h, int32_t enabled);
@@ -176,6 +192,7 @@ typedef enum d2d_tuning {
     D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
     D2D_TUNE_OBS_BLOCK = 3,        /* threads per obs workgroup; 0 = auto                            */
     D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): T staged in LDS; 1: T read from global (A/B)      */
+    D2D_TUNE_OBS_STAGGER = 16,     /* A/B: wave w of an obs workgroup sleeps w * value * 64 clocks before its stores; 0 (default) off */
     D2D_TUNE_STEP_THREADS = 5,     /* threads per ENV in the step kernel; 0 = auto (one per link).  Below half the link
                                       count no link sits in registers (strided kernel) and the per-RB search
                                       structures give way to the O(N^2) sweep                              */
@@ -303,6 +320,13 @@ int d2d_profile_reset(d2d_handle* h);
 int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s,
                              double* per_variant, int32_t n);
 int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s);
+/* One member of the family with the obs kernel's TIMING structure added: variant = the geometry index above
+ * + 32 (every workgroup first stages one row of a table through LDS behind a barrier and stores what it reads
+ * back) + 64 (wave w sleeps w * stagger * 64 clocks before its first store).  dst_dev = NULL writes a scratch
+ * buffer of `bytes`; a device pointer writes THAT memory (e.g. the obs block itself: same pages, same
+ * footprint as the kernel being explained).                                                              */
+int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters,
+                           double* gb_per_s);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,42 @@ def _modes_worker(rank, world, port, out_dir):
             want = torch.stack([torch.cat([local(r, s)[0][:, 0] for r in range(world)]) for s in range(step - 2, step + 1)])
             if sig is not None or g.reward_step != step - 2 or not torch.equal(block, want):
                 errors.append(f'reward ring block ending at step {step}')
+    # a rollout that ends inside a block: flush() gathers the partly filled ring and says how many rows are valid
+    g = StepGatherer(b, n, dev, mode='rewards', reward_every=4)
+    for step in range(6):
+        g.launch(*local(rank, step))
+    valid = g.flush()
+    block, _ = g.wait()
+    want = torch.stack([torch.cat([local(r, s)[0][:, 0] for r in range(world)]) for s in (4, 5)])
+    if valid != 2 or g.reward_step != 4 or not torch.equal(block[:2], want) or g.flush() != 0:
+        errors.append('flush of a partial reward ring')
+    for step in range(6, 10):                            # the next block starts clean after a flush
+        g.launch(*local(rank, step))
+    block, _ = g.wait()
+    want = torch.stack([torch.cat([local(r, s)[0][:, 0] for r in range(world)]) for s in range(6, 10)])
+    if g.reward_step != 6 or not torch.equal(block, want):
+        errors.append('reward ring block after a flush')
+    # mode 'planes': the (sinr, snr) planes and the link-position rows travel instead of the table; per-env reward vector;
+    # the assembled table is bit-identical to the table plan's
+    gt = StepGatherer(b, n, dev)
+    gp = StepGatherer(b, n, dev, mode='planes')
+    reward, table = local(rank, 5)
+    table = table + torch.arange(b * n * 6, dtype=torch.float32).reshape(b, n, 6)
+    gt.gather_positions(table)
+    gp.gather_positions(table[:, :, :4].contiguous())    # D2D_BUF_LINK_POS rows
+    gt.launch(reward, table)
+    gp.launch(reward[:, 0].contiguous(), sinr=table[:, :, 4].contiguous(), snr=table[:, :, 5].contiguous())
+    rt, _ = gt.wait()
+    rp, planes = gp.wait()
+    if not torch.equal(rt, rp) or not torch.equal(gt.table(), gp.table()) or tuple(planes[0].shape) != (world * b, n):
+        errors.append('planes mode differs from the table plan')
+    if gp.bytes_per_signal_launch != b * 4 + b * n * 8:
+        errors.append('planes mode byte count')
+    try:
+        gp.launch(reward)                                # planes missing
+        errors.append('planes mode without planes did not raise')
+    except ValueError:
+        pass
     try:
         StepGatherer(b, n, dev, reward_every=2)          # mode 'table': not allowed
         errors.append('reward_every with mode table did not raise')
@@ -214,6 +250,25 @@ def test_bench_self_launches_eight_ranks():
     assert line['allgather_envs'] == 16 and line['checksums_agree'] is True and len(line['per_rank']) == 8
     assert line['gather']['mode'] == 'rewards' and line['gather']['bytes_per_gpu_per_step'] == 2 * 4 and line['gather']['reward_every'] == 4
     assert abs(line['value_per_gpu'] * 8 - line['value']) < 1e-6 * line['value']
+
+
+def test_bench_launcher_deadline_ends_a_job_with_a_stuck_rank():
+    """One rank never arrives (stuck before / in a collective): --rank-timeout ends the job - the launcher terminates its own
+    children by PID and exits 124 - in well under twice the deadline, instead of holding the node until the driver's limit."""
+    import time
+    t0 = time.monotonic()
+    r, out = _run_bench(['--gpus', '2', '--stub-cpu', '--steps', '2', '--warmup', '1', '--envs', '4', '--workload', 'default',
+                         '--rank-timeout', '20'], env_extra={'D2D_BENCH_TEST_HANG_RANK': '1'}, timeout=120)
+    took = time.monotonic() - t0
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    assert 'still running after --rank-timeout' in r.stderr and took < 40.0, took
+    assert not any(isinstance(o, dict) for o in out)             # no result line from a job that did not finish
+
+
+def test_bench_n_gt_1_line_says_where_the_cpu_baseline_is():
+    r, out = _run_bench(['--gpus', '2', '--stub-cpu', '--steps', '2', '--warmup', '1', '--envs', '4', '--workload', 'default'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out[0]['cpu_baseline'].startswith('N=1 line only')
 
 
 def test_bench_launcher_propagates_a_failing_rank():

@@ -215,7 +215,18 @@ def test_plugin_lowering_choices(stub):
     assert not any(n in ('power_law', 'shadowing') for n, _ in stub.instances[-1].calls)
     env.reset()
     table, = stub.instances[-1].last('table')
-    assert table.shape == (4, 4) and np.isnan(table[0, 0]) and table[0, 1] == 100.0
+    # only (transmitter of a link) x (receiver of a link) pairs are evaluated: cue00 -> mbs, due00 -> due01 and their cross terms
+    assert table.shape == (4, 4) and table.dtype == np.float64 and np.isnan(table[0, 0])
+    assert table[1, 0] == 100.0 and table[2, 3] == 100.0 and table[1, 3] == 100.0 and table[2, 0] == 100.0
+    assert np.isnan(table[0, 1]) and np.isnan(table[3, 2])                     # the BS / a DUE receiver never transmit here
+    # a changed link list (downlink mbs -> cue00) adds the pairs it needs, keeps the rest
+    calls = []
+    orig = Custom.__call__
+    Custom.__call__ = lambda self, tx, rx: (calls.append((tx.id, rx.id)), 100.0)[1]
+    env.step({'mbs:cue00': 3, 'due00:due01': 5})
+    Custom.__call__ = orig
+    table, = stub.instances[-1].last('table')
+    assert table[0, 1] == 100.0 and table[0, 3] == 100.0 and table[2, 1] == 100.0 and table[1, 0] == 100.0
 
 
 def test_save_device_config_format(stub, tmp_path):

@@ -20,6 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--state', default='fresh')
 ap.add_argument('--steps', type=int, default=12)
 ap.add_argument('--time', action='store_true')
+ap.add_argument('--own', default='', help="'obs' / 'all': these buffers are handed back to the library (its own hipMalloc) instead of torch tensors")
+ap.add_argument('--rotate', type=int, default=-1)
 a = ap.parse_args()
 
 big = None
@@ -38,6 +40,15 @@ if a.state != 'fresh':
             torch.cuda.empty_cache()
 
 env = VecD2DEnv({'num_rbs': 25, 'num_cues': 25, 'num_due_pairs': 25}, num_envs=1024, cue_actions='traffic')
+h = env.simulator.handle
+from gym_d2d_amd import _native
+if a.own:
+    which = [_native.BUF_OBS] if a.own == 'obs' else [_native.BUF_OBS, _native.BUF_OBS_TABLE, _native.BUF_SINR_DB, _native.BUF_SNR_DB,
+                                                       _native.BUF_RATE_BPS, _native.BUF_CAPACITY, _native.BUF_REWARD, _native.BUF_RB, _native.BUF_PWR]
+    for w in which:
+        h.bind_buffer(w, 0, 0)                  # unbound: the library allocates its own on the next step
+if a.rotate >= 0:
+    h.set_tuning(_native.TUNE_STEP_OBS_ROTATE, a.rotate)
 env.reset(seed=1)
 acts = torch.randint(0, 25 * 21, (8, 1024, 25), device=env.device, dtype=torch.int32)
 if a.time:
@@ -51,7 +62,9 @@ if a.time:
             env.step(acts[k % 8])
         torch.cuda.synchronize()
         res.append(round((time.perf_counter() - t0) / 200 * 1e6, 2))
-    print(json.dumps({'state': a.state, 'us_per_step': res, 'mem_reserved_GB': round(torch.cuda.memory_reserved() / 1e9, 2)}), flush=True)
+    obs_ptr = h.get_buffer(_native.BUF_OBS)[0]
+    print(json.dumps({'state': a.state, 'own': a.own, 'rotate': a.rotate, 'obs_ptr_mod_2MiB': obs_ptr % (2 << 20), 'obs_ptr_GiB': round(obs_ptr / 2**30, 3),
+                      'us_per_step': res, 'mem_reserved_GB': round(torch.cuda.memory_reserved() / 1e9, 2)}), flush=True)
 else:
     for k in range(a.steps):
         env.step(acts[k % 8])

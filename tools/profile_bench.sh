@@ -4,7 +4,8 @@
 # Writes raw output under gpurun_out/prof_<tag>_<workload>_<obs>/ and the condensed summaries into profiles/.
 tag=$1; wl=$2; obs=$3; steps=${4:-100}; extra="${@:5}"
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/prof_${tag}_${wl}_${obs}
+sfx=$(echo "$extra" | tr -cd 'a-z')
+out=$R/gpurun_out/prof_${tag}_${wl}_${obs}${sfx:+_$sfx}
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 args="--workload $wl --obs $obs --no-cpu-baseline --no-single-env-latency --no-extras $extra"

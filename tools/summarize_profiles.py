@@ -29,14 +29,41 @@ def counters(raw, sub):
     return acc
 
 
+def durations(raw, skip_first):
+    """Per d2d kernel, from the kernel trace of the --stats run: launch durations in dispatch order with the first
+    `skip_first` launches of every kernel (warm-up, page touching) left out - median and mean of the rest beside rocprofv3's
+    own all-launch average."""
+    per = collections.defaultdict(list)
+    for f in glob.glob(f'{raw}/kt/**/*kernel_trace.csv', recursive=True):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+        for r in rows:
+            if 'd2d::' in r['Kernel_Name']:
+                per[r['Kernel_Name'][:70]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    out = {}
+    for k, v in per.items():
+        rest = sorted(v[skip_first:]) if len(v) > 2 * skip_first else sorted(v)
+        out[k] = {'launches': len(v), 'warmup_launches_excluded': len(v) - len(rest), 'median_us': round(rest[len(rest) // 2], 3),
+                  'mean_us': round(sum(rest) / len(rest), 3), 'min_us': round(rest[0], 3), 'max_us': round(rest[-1], 3),
+                  'mean_us_all_launches': round(sum(v) / len(v), 3)}
+    return out
+
+
 def main():
     tag, wl, obs, raw = sys.argv[1:5]
     extra = ' '.join(sys.argv[5:])                    # extra bench arguments the passes ran with, e.g. --no-export
+    # one summary per CONFIGURATION: the compact modes with / without the decoded (rb, pwr) planes and with the per-env reward
+    # differ in their bytes per link (file names of rounds 1-3: the table mode's summary is the --no-export one)
+    suffix = ''
+    key_obs = obs
+    if '--reward-per-env' in extra:
+        suffix += '_per_env_reward'; key_obs += '_per_env_reward'
+    if obs != 'linear' and '--no-export' not in extra:
+        suffix += '_export'
     from gym_d2d_amd.build import source_digest
     stats = glob.glob(f'{raw}/kt/**/*kernel_stats.csv', recursive=True)
     if stats:
         rows = list(csv.reader(open(stats[0])))
-        out = ROOT / 'profiles' / f'{tag}_kernel_stats_{wl}_{obs}.csv'
+        out = ROOT / 'profiles' / f'{tag}_kernel_stats_{wl}_{obs}{suffix}.csv'
         with open(out, 'w', newline='') as f:
             w = csv.writer(f)
             for r in rows:
@@ -70,10 +97,11 @@ def main():
                 d['wait_any_fraction_of_wave_cycles'] = round(sq.get('SQ_WAIT_ANY', 0.0) / sq['SQ_WAVE_CYCLES'], 3)
     rec = {'command': 'tools/profile_bench.sh: rocprofv3 --pmc <one counter set per pass> --output-format csv -- python3 bench.py '
                       f'--workload {wl} --obs {obs} --no-cpu-baseline --no-single-env-latency --no-extras {extra} --steps 5 --warmup 1'.replace('  ', ' '),
-           'workload_key': f'{wl}/{obs}', 'source_digest': source_digest(), 'kernels': kernels}
-    out = ROOT / 'profiles' / f'{tag}_pmc_{wl}_{obs}.json'
+           'workload_key': f'{wl}/{key_obs}', 'source_digest': source_digest(), 'kernels': kernels,
+           'kernel_trace_durations': durations(raw, 12)}
+    out = ROOT / 'profiles' / f'{tag}_pmc_{wl}_{obs}{suffix}.json'
     out.write_text(json.dumps(rec, indent=1))
-    if (wl, obs) == ('stress', 'table'):
+    if (wl, obs) == ('stress', 'table') and suffix == '':
         # the step kernel is 100 % of this mode's step: its own summary under the name VERDICT r1 asked for
         step = {k: d for k, d in kernels.items() if 'step_kernel' in k}
         for k, d in step.items():
@@ -86,6 +114,8 @@ def main():
                                                                              1024 * d.get('WRITE_SIZE_KiB_mean_per_launch', 0.0)],
                             'algorithmic bytes per launch (4096 x 512 x 64)': 4096 * 512 * 64}
         (ROOT / 'profiles' / f'{tag}_pmc_step_kernel.json').write_text(json.dumps(dict(rec, kernels=step), indent=1))
+    for k, d in rec['kernel_trace_durations'].items():
+        print(k[:60], d)
     for k, d in kernels.items():
         print(k[:60], {a: (round(b) if isinstance(b, float) else b) for a, b in d.items() if not isinstance(b, dict)})
 
