@@ -30,6 +30,8 @@ FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
  TUNE_STEP_OBS_ROTATE, TUNE_OBS_STAGGER) = range(17)
 # d2d_reward_layout
 REWARD_PER_AGENT, REWARD_PER_ENV = 0, 1
+# d2d_dtype
+F32, F64 = 0, 1
 UNIQUE_ID_BYTES = 128
 
 BUFFER_DTYPES = {BUF_ACTIONS: np.int32, BUF_RB: np.int32, BUF_PWR: np.int32, BUF_ENV_FLAGS: np.int32}
@@ -81,6 +83,7 @@ SIGNATURES = {
     'd2d_set_reward': (C.c_int, [_P, _I, C.c_float]),
     'd2d_set_obs_mode': (C.c_int, [_P, _I]),
     'd2d_set_reward_layout': (C.c_int, [_P, _I]),
+    'd2d_set_obs_dtype': (C.c_int, [_P, _I]),
     'd2d_set_bucketing': (C.c_int, [_P, _I]),
     'd2d_set_export_actions': (C.c_int, [_P, _I]),
     'd2d_set_tuning': (C.c_int, [_P, _I, _I]),
@@ -220,6 +223,11 @@ class Handle:
     def set_obs_mode(self, mode: int) -> None:
         _check(self._lib.d2d_set_obs_mode(self._h, mode))
 
+    def set_obs_dtype(self, dtype: int) -> None:
+        """F64: D2D_BUF_OBS is float64 [B,N,6N], widened by the expansion kernel itself (the reference's dtype, obs_fn.py:51)."""
+        _check(self._lib.d2d_set_obs_dtype(self._h, dtype))
+        self.obs_f64 = dtype == F64
+
     def set_reward_layout(self, layout: int) -> None:
         """REWARD_PER_ENV: SystemCapacity's scalar once per env (BUF_REWARD_ENV [B]) instead of N copies (BUF_REWARD [B,N])."""
         _check(self._lib.d2d_set_reward_layout(self._h, layout))
@@ -265,7 +273,8 @@ class Handle:
     def download(self, which: int, env_begin: int = 0, env_count: Optional[int] = None) -> np.ndarray:
         shape = self.buffer_shape(which)
         env_count = self.num_envs - env_begin if env_count is None else env_count
-        out = np.empty((env_count,) + shape[1:], dtype=BUFFER_DTYPES.get(which, np.float32))
+        dtype = np.float64 if which == BUF_OBS and getattr(self, 'obs_f64', False) else BUFFER_DTYPES.get(which, np.float32)
+        out = np.empty((env_count,) + shape[1:], dtype=dtype)
         per_env = out.nbytes // max(env_count, 1)
         if out.nbytes:
             _check(self._lib.d2d_download(self._h, which, out.ctypes.data_as(_P), out.nbytes, env_begin * per_env))

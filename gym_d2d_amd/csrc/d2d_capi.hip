@@ -95,6 +95,7 @@ struct d2d_handle {
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
     int export_actions = 1;                          // d2d_step writes the decoded (rb, pwr) to D2D_BUF_RB / D2D_BUF_PWR
+    int obs_f64 = 0;                                 // D2D_BUF_OBS holds float64 (d2d_set_obs_dtype)
     int reward_layout = D2D_REWARD_PER_AGENT;        // SystemCapacity: [B,N] rows or one scalar per env (D2D_BUF_REWARD_ENV)
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0, tune_stagger = 0;
     int num_cus = 0;
@@ -130,7 +131,7 @@ size_t active_bytes(const d2d_handle* h, int which, int n_links) {
     switch (which) {
         case D2D_BUF_POS_X: case D2D_BUF_POS_Y: return B * D * 4;
         case D2D_BUF_OBS_TABLE: return B * N * 6 * 4;
-        case D2D_BUF_OBS: return B * N * 6 * N * 4;
+        case D2D_BUF_OBS: return B * N * 6 * N * (h->obs_f64 ? 8 : 4);
         case D2D_BUF_ENV_FLAGS: case D2D_BUF_REWARD_ENV: return B * 4;
         case D2D_BUF_LINK_POS: return B * N * 16;
         default: return B * N * 4;
@@ -342,6 +343,7 @@ void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float*
     o.block = block;
     o.variant = h->tune_variant;
     o.stagger = h->tune_stagger;
+    o.out_f64 = 0;
     o.table = table;
     o.obs = obs;
     *out = o;
@@ -405,7 +407,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     int fuse = 0;
     if (h->obs_mode == D2D_OBS_LINEAR) {
         const bool want = h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128;
-        if (want) fuse = (6 * N) % 4 == 0 ? 4 : 2;
+        if (want && !h->obs_f64) fuse = (6 * N) % 4 == 0 ? 4 : 2;       // the fused expansion writes float32 only
     }
     // per-RB membership masks: u32 words, every link of the env in some thread's registers, N <= 1024 (the 32-bit summary
     // word names up to 32 mask words)
@@ -525,6 +527,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     if (h->obs_mode == D2D_OBS_LINEAR && !fuse) {
         d2d::ObsArgs o;
         make_obs_args(h, h->B, N, s.table, s.obs, &o);
+        o.out_f64 = redirect ? 0 : h->obs_f64;                          // d2d_step_host's packed block is float32
         rc = record_start(h, 1, &ep);
         if (rc) return rc;
         HIP_TRY(d2d::launch_obs_expand(o, h->stream));
@@ -804,6 +807,18 @@ int d2d_set_reward_layout(d2d_handle* h, int32_t layout) {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     if (layout != D2D_REWARD_PER_AGENT && layout != D2D_REWARD_PER_ENV) return fail(D2D_ERR_INVALID, "unknown reward layout");
     h->reward_layout = layout;
+    return D2D_OK;
+}
+
+int d2d_set_obs_dtype(d2d_handle* h, int32_t dtype) {
+    if (!h) return fail(D2D_ERR_INVALID, "null handle");
+    if (dtype != D2D_F32 && dtype != D2D_F64) return fail(D2D_ERR_INVALID, "obs dtype must be D2D_F32 or D2D_F64");
+    USE_DEVICE(h);
+    if ((dtype == D2D_F64) != (h->obs_f64 != 0)) {
+        Buffer& bf = h->buf[D2D_BUF_OBS];                             // an owned block of the other width is dropped; a bound one is re-checked at the next step
+        if (bf.ptr && bf.owned) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(bf.ptr)); bf.ptr = nullptr; bf.bytes = 0; }
+    }
+    h->obs_f64 = dtype == D2D_F64;
     return D2D_OK;
 }
 

@@ -105,6 +105,7 @@ struct ObsArgs {
     int nontemporal;
     int block;               // threads per workgroup (0 -> 256)
     int variant;             // 0: T staged in LDS   1: T read straight from global (A/B)
+    int out_f64;             // obs is float64 [B,N,6N] (d2d_set_obs_dtype): obs_expand_f64_kernel
     int stagger;             // > 0: wave w of a workgroup sleeps w * stagger x 64 clocks before its stores (A/B)
     const float* table;      // [B,N,6]
     float* obs;              // [B,N,6N]

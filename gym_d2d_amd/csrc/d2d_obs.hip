@@ -104,6 +104,49 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     }
 }
 
+// The same expansion written as float64 (d2d_set_obs_dtype: the reference's observation dtype, obs_fn.py:47,51 builds float64
+// arrays): every aligned float2 of T becomes one 16-byte double2 store, so the widening happens on the way out and the [B,N,6N]
+// block is written once - 48 N bytes per agent-step instead of 24 N written, 24 N re-read and 48 N written by a separate cast.
+template <bool NT>
+__global__ __launch_bounds__(1024) void obs_expand_f64_kernel(const ObsArgs a) {
+    extern __shared__ __align__(16) float t_flat[];          // [6N]
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
+    unsigned env, chunk;
+    if (a.xcd_remap) {
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3, G = (unsigned)a.xcd_remap;
+        const unsigned per_group = a.chunks * G, group = rest / per_group, within = rest % per_group;
+        chunk = within / G;
+        env = (group * G + within % G) * 8u + lane8;
+    } else {
+        env = blockIdx.x / a.chunks;
+        chunk = blockIdx.x % a.chunks;
+    }
+    const unsigned row_floats = 6u * N, q2 = row_floats / 2u;
+    {
+        const f32x2* src = reinterpret_cast<const f32x2*>(a.table + (size_t)env * row_floats);
+        f32x2* dst = reinterpret_cast<f32x2*>(t_flat);
+        for (unsigned k = tid; k < q2; k += T) dst[k] = src[k];
+    }
+    __syncthreads();
+    const unsigned r0 = chunk * a.rows_per_wg;
+    const unsigned r1 = min(r0 + (unsigned)a.rows_per_wg, N);
+    const f32x2* t2 = reinterpret_cast<const f32x2*>(t_flat);
+    double* out = reinterpret_cast<double*>(a.obs) + ((size_t)env * N + r0) * row_floats;
+    for (unsigned i = r0; i < r1; ++i) {
+        const unsigned head = 6u * i;
+        f64x2* o = reinterpret_cast<f64x2*>(out + (size_t)(i - r0) * row_floats);
+#pragma unroll 2
+        for (unsigned c = tid; c < q2; c += T) {
+            const unsigned f = 2u * c;
+            const f32x2 v = t2[src_col(f, i) >> 1];
+            const f64x2 d = {(double)v.x, (double)v.y};
+            if (NT) __builtin_nontemporal_store(d, o + c); else o[c] = d;
+        }
+        (void)head;
+    }
+}
+
 // Variant without LDS staging or barrier (float4 rows only): every thread fetches its two source float2 straight
 // from T in global memory (L1 / the XCD's L2 after the first touch) and stores.  Selected by D2D_TUNE_OBS_VARIANT=1;
 // kept for A/B measurement against the staged kernel (tools/tune_obs.py).
@@ -141,6 +184,11 @@ __global__ __launch_bounds__(1024) void obs_expand_direct_kernel(const ObsArgs a
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.N * 6 * sizeof(float);
     dim3 grid((unsigned)a.B * (unsigned)a.chunks), block(a.block > 0 ? a.block : 256);
+    if (a.out_f64) {
+        if (a.nontemporal) hipLaunchKernelGGL(obs_expand_f64_kernel<true>, grid, block, lds, stream, a);
+        else hipLaunchKernelGGL(obs_expand_f64_kernel<false>, grid, block, lds, stream, a);
+        return hipGetLastError();
+    }
     if (a.variant == 1 && a.vec == 4) {
         hipLaunchKernelGGL(obs_expand_direct_kernel, grid, block, 0, stream, a);
         return hipGetLastError();

@@ -113,6 +113,10 @@ class VecD2DEnv:
         h.set_export_actions(self.export_actions)
         self._obs64 = cfg.obs_dtype == 'float64'
         h.set_obs_mode(self.obs_fn.native_mode)
+        # float64 observations of the native LinearObs: the expansion kernel writes them as float64 itself (no cast pass)
+        self._native_obs64 = self._obs64 and self.obs_fn.native_mode == _native.OBS_LINEAR and not isinstance(self.obs_fn, ArrayObsFunction)
+        if self._native_obs64:
+            h.set_obs_dtype(_native.F64)
         h.set_reward(rid, float(getattr(self.reward_fn, 'native_param', 0.0)))
         self._native_reward = bool(rid)
         self.reward_per_env = bool(reward_per_env)
@@ -159,7 +163,7 @@ class VecD2DEnv:
             self._t['table'] = None                        # D2D_OBS_NONE: no table exists; positions: link_positions()
         self._t['env_flags'] = alloc(_native.BUF_ENV_FLAGS, (b,), torch.int32)
         if self.obs_fn.native_mode == _native.OBS_LINEAR:
-            self._t['obs'] = alloc(_native.BUF_OBS, (b, n, 6 * n), torch.float32)
+            self._t['obs'] = alloc(_native.BUF_OBS, (b, n, 6 * n), torch.float64 if self._native_obs64 else torch.float32)
         self._stream_ptr = None
         # the raw current-stream query (one C call, no Stream object) when this torch has it
         raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -269,7 +273,7 @@ class VecD2DEnv:
 
     def _observe(self, view):
         obs = self.obs_fn.compute(view) if self._array_obs else view.obs
-        if self._obs64:                                   # the reference's dtype (obs_fn.py:51), on request
+        if self._obs64 and not self._native_obs64 and not isinstance(obs, tuple):   # the reference's dtype (obs_fn.py:51) for a custom array obs: cast here
             obs = obs.double() if self.use_torch else np.asarray(obs, dtype=np.float64)
         return obs
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 3      /* 3: double path-loss tables, per-env reward, link-position rows, staged write probe */
+#define D2D_ABI_VERSION 3      /* 3: double path-loss tables, per-env reward, link-position rows, f64 obs, staged write probe */
 #define D2D_MAX_LINKS 2048      /* links per env the step kernel's LDS staging is sized for */
 #define D2D_UNIQUE_ID_BYTES 128 /* size of an RCCL unique id (ncclUniqueId)                  */
 
@@ -71,7 +71,7 @@ typedef enum d2d_buffer {
     D2D_BUF_CAPACITY = 8,   /* f32 [B,N]   state['capacity_mbps']  (simulator.py:144-154)           */
     D2D_BUF_REWARD = 9,     /* f32 [B,N]   per-agent reward        (reward_fn.py)                   */
     D2D_BUF_OBS_TABLE = 10, /* f32 [B,N,6]                          (obs_fn.py:55-61)               */
-    D2D_BUF_OBS = 11,       /* f32 [B,N,6N]                         (obs_fn.py:43-53)               */
+    D2D_BUF_OBS = 11,       /* f32 [B,N,6N] (f64 under d2d_set_obs_dtype(D2D_F64))  (obs_fn.py:43-53) */
     D2D_BUF_ENV_FLAGS = 12, /* i32 [B]     D2D_FLAG_* bits raised by the last step                  */
     D2D_BUF_LINK_POS = 13,  /* f32 [B,N,4] (tx_x,tx_y,rx_x,rx_y) of every link = columns 0-3 of the obs
                                table (obs_fn.py:57-59).  READ-ONLY, library-owned (cannot be bound or
@@ -169,6 +169,13 @@ int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_id
 /* RewardFunction / ObsFunction plugin selection (d2d_env.py:27-28).                                */
 int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param);
 int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode);
+/* Element type of D2D_BUF_OBS under D2D_OBS_LINEAR.  D2D_F32 (default): the kernels' own type.  D2D_F64: the reference's
+ * (LinearObsFunction builds float64 arrays, obs_fn.py:47,51) - the expansion kernel widens on the way out, so the block
+ * is written once (48 N bytes per agent-step) instead of being cast by the caller afterwards (24 N written, 24 N read
+ * back, 48 N written).  D2D_BUF_OBS is then f64 [B,N,6N] (twice the bytes; a bound buffer must be that large) and the
+ * expansion always runs as its own launch.  d2d_step_host's packed block and d2d_expand_table stay float32.             */
+typedef enum d2d_dtype { D2D_F32 = 0, D2D_F64 = 1 } d2d_dtype;
+int d2d_set_obs_dtype(d2d_handle* h, int32_t dtype);
 /* SystemCapacityRewardFunction hands the SAME scalar to every agent of an env (reward_fn.py:42-44).
  * D2D_REWARD_PER_AGENT (default): d2d_step writes it N times, D2D_BUF_REWARD f32 [B,N] - the dict the
  * reference returns.  D2D_REWARD_PER_ENV: written once per env to D2D_BUF_REWARD_ENV f32 [B]; D2D_BUF_REWARD

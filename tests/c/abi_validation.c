@@ -46,6 +46,7 @@ int main(void) {
     EXPECT_ERR(d2d_set_reward(NULL, 1, 0.0f));
     EXPECT_ERR(d2d_set_reward_layout(NULL, 0));
     EXPECT_ERR(d2d_set_obs_mode(NULL, 1));
+    EXPECT_ERR(d2d_set_obs_dtype(NULL, D2D_F64));
     EXPECT_ERR(d2d_set_bucketing(NULL, 1));
     EXPECT_ERR(d2d_set_export_actions(NULL, 1));
     EXPECT_ERR(d2d_set_tuning(NULL, 0, 0));
@@ -116,6 +117,7 @@ int main(void) {
     EXPECT_ERR(d2d_set_reward(h, 9, 0.0f));
     EXPECT_ERR(d2d_set_reward_layout(h, 2));
     EXPECT_ERR(d2d_set_obs_mode(h, 3));
+    EXPECT_ERR(d2d_set_obs_dtype(h, 9));
     EXPECT_ERR(d2d_set_tuning(h, 999, 0));
     EXPECT_ERR(d2d_set_tuning(h, D2D_TUNE_STEP_BLOCK, 100));
     EXPECT_ERR(d2d_get_buffer(h, D2D_BUF_COUNT, &p, &n));

@@ -340,3 +340,32 @@ def test_lists_are_not_taken_automatically_where_they_cannot_help(native):
                          orc.device_columns(*orc.device_configs(cues, dues)[1:]), orc.PathLossSpec(), with_obs=False)
     assert rel_err(auto['BUF_SINR_DB'], want['sinr_db']) <= TOL
     sim.handle.close()
+
+
+@pytest.mark.parametrize('shape', [(5, 7, 24, 25), (9, 25, 25, 25), (3, 256, 256, 256), (2, 30, 301, 300)])
+def test_float64_obs_is_written_by_the_expansion_kernel_itself(native, shape):
+    """d2d_set_obs_dtype(D2D_F64): D2D_BUF_OBS is float64 [B, N, 6N] with exactly the float32 values (obs_fn.py:51 builds
+    float64 arrays); switching back and forth re-sizes the library's own block; a bound block that is too small is refused."""
+    import torch
+    b, rbs, cues, dues = shape
+    n = cues + dues
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=sum(shape) + 4)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_LINEAR)
+    sim.step_arrays(raw)
+    o32 = sim.fetch(native.BUF_OBS).copy()
+    h.set_obs_dtype(native.F64)
+    sim.step_arrays(raw)
+    o64 = sim.fetch(native.BUF_OBS)
+    assert o64.dtype == np.float64 and o64.shape == (b, n, 6 * n) and np.array_equal(o64, o32.astype(np.float64))
+    small = torch.empty(b * n * 6 * n, dtype=torch.float32, device='cuda')
+    h.bind_buffer(native.BUF_OBS, small.data_ptr(), small.numel() * 4)      # float32-sized: too small for float64
+    with pytest.raises(native.NativeError):
+        sim.step_arrays(raw)
+    h.set_obs_dtype(native.F32)
+    sim.step_arrays(raw)
+    torch.cuda.synchronize()
+    assert np.array_equal(small.cpu().numpy().reshape(b, n, 6 * n), o32)
+    with pytest.raises(native.NativeError):
+        h.set_obs_dtype(7)
+    sim.handle.close()
