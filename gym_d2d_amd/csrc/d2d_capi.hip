@@ -964,6 +964,29 @@ int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
     return D2D_OK;
 }
 
+int d2d_block_alloc(int32_t device_ordinal, size_t bytes, void** dev_ptr) {
+    if (!dev_ptr || bytes == 0) return fail(D2D_ERR_INVALID, "bad argument");
+    *dev_ptr = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device_ordinal < 0 || device_ordinal >= count) return fail(D2D_ERR_HIP, "device_ordinal out of range (no usable GPU?)");
+    DeviceGuard guard(device_ordinal);
+    if (guard.err != hipSuccess) return fail(D2D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+    HIP_TRY(hipMalloc(dev_ptr, bytes));
+    return D2D_OK;
+}
+
+int d2d_block_free(int32_t device_ordinal, void* dev_ptr) {
+    if (!dev_ptr) return D2D_OK;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device_ordinal < 0 || device_ordinal >= count) return fail(D2D_ERR_HIP, "device_ordinal out of range (no usable GPU?)");
+    DeviceGuard guard(device_ordinal);
+    if (guard.err != hipSuccess) return fail(D2D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+    HIP_TRY(hipFree(dev_ptr));                      // synchronises with the work that may still use the block
+    return D2D_OK;
+}
+
 int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes, size_t dst_offset) {
     if (!h || !host_src) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
     const int cfg_col_mode = HOT ? 0 : a.col_mode;
     const int cfg_reward_fn = HOT ? 1 : a.reward_fn;
-    const int cfg_write_table = HOT ? 1 : a.write_table;
+    const int cfg_write_table = HOT == 2 ? 1 : a.write_table;     // HOT 1 serves D2D_OBS_TABLE and D2D_OBS_NONE (one uniform branch around three stores)
     // (the flattened walk is an A/B shape of the power-law kernels: the table / shadowing kernels, whose pair evaluation is
     // hundreds of instructions, carry the nested one only)
     const int cfg_walk = (HOT || LISTS || MODE == PL_SHADOW || MODE == PL_TABLE) ? 0 : a.walk;
@@ -1121,7 +1121,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const int lpt = a.lpt;
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
     const bool lists = a.walk == 2 && lpt > 0 && a.reward_fn != 3;
-    const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 && a.write_table &&
+    const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 &&
                      a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
     const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0);

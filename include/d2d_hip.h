@@ -235,6 +235,13 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
 int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes);
 /* Use caller-owned device memory for a buffer (e.g. a torch tensor); never freed by the library.   */
 int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes);
+/* A device block that is an allocation OF ITS OWN (one hipMalloc, released by d2d_block_free) for a caller that binds
+ * buffers.  Why the library offers this: the small workload's fused step ran 11 % slower whenever its 61 MB obs block
+ * was a PIECE of a large allocation - a framework's caching allocator re-using a 26 GB block - than as a dedicated
+ * allocation, with identical TLB and L2-channel counters (profiles/r4_context_*); a dedicated block makes
+ * the step independent of what the process allocated before.  VecD2DEnv keeps D2D_BUF_OBS in one.                      */
+int d2d_block_alloc(int32_t device_ordinal, size_t bytes, void** dev_ptr);
+int d2d_block_free(int32_t device_ordinal, void* dev_ptr);
 /* Synchronous host<->device copies (ordered after queued work on the handle's stream).             */
 int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes, size_t dst_offset);
 int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset);

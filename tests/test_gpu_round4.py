@@ -369,3 +369,37 @@ def test_float64_obs_is_written_by_the_expansion_kernel_itself(native, shape):
     with pytest.raises(native.NativeError):
         h.set_obs_dtype(7)
     sim.handle.close()
+
+
+def test_rollout_kernel_serves_the_obs_less_mode(native):
+    """HOT level 1 (one env per workgroup, N a multiple of 64) with D2D_OBS_NONE, per-env reward and no decoded (rb, pwr)
+    planes - the learner configuration - against the generic kernel (action prefetch off is one of the specialisation's
+    conditions): every output bit for bit; the table buffer is never touched."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    from gym_d2d_amd.envs.obs_fn import SignalPlanesObsFunction
+    B, C, P, R = 41, 64, 64, 16
+    outs = {}
+    for prefetch in (-1, 0):
+        env = VecD2DEnv({'num_rbs': R, 'num_cues': C, 'num_due_pairs': P, 'obs_fn': SignalPlanesObsFunction}, num_envs=B,
+                        export_actions=False, reward_per_env=True)
+        h = env.simulator.handle
+        canary = torch.full((B * (C + P) * 6,), 7.5, dtype=torch.float32, device=env.device)
+        h.bind_buffer(native.BUF_OBS_TABLE, canary.data_ptr(), canary.numel() * 4)
+        env.reset(seed=21)
+        h.set_tuning(native.TUNE_STEP_PREFETCH, prefetch)
+        g = torch.Generator(device=env.device).manual_seed(3)
+        snaps = []
+        for k in range(3):
+            act = torch.randint(0, R * 21, (B, C + P), device=env.device, generator=g, dtype=torch.int32)
+            (sinr, snr), rew, _, info = env.step(act)
+            torch.cuda.synchronize()
+            snaps.append({n: v.clone() for n, v in dict(info, rew=rew, sinr=sinr, snr=snr, flags=env._t['env_flags']).items() if torch.is_tensor(v)})
+        assert (canary == 7.5).all()
+        outs[prefetch] = snaps
+        env.close()
+    for k in range(3):
+        for n, v in outs[-1][k].items():
+            w = outs[0][k][n]
+            assert torch.equal(v.view(torch.int32) if v.is_floating_point() else v, w.view(torch.int32) if w.is_floating_point() else w), (k, n)
+    assert tuple(outs[-1][0]['rew'].shape) == (B,)
