@@ -348,7 +348,7 @@ class Session:
     """One workload on this rank's GPU: the env, its pre-generated actions and the timing loops."""
 
     def __init__(self, torch, args, key, obs, dev, rank, local, steps, warmup, *, envs=0, cue_mode='', tune='', stub=False,
-                 export=True):
+                 export=True, action_pool=0):
         self.torch, self.args, self.key, self.obs, self.dev, self.rank, self.stub = torch, args, key, obs, dev, rank, stub
         self.export = export
         w = dict(WORKLOADS[key])
@@ -395,11 +395,13 @@ class Session:
         g.manual_seed(1234 + rank)
         pc, pd = self.env.num_pwr_actions['cue'], self.env.num_pwr_actions['due']
         # actions of the links the AGENTS drive: [total, B, C+P], or DUE-only [total, B, P] when the CUEs follow the traffic model
-        self.actions = torch.empty((self.total, b, self.n_agents), dtype=torch.int32, device=dev)
+        # (action_pool > 0: that many distinct action tensors, walked round-robin - long runs of a large workload)
+        self.pool = pool = min(action_pool, self.total) if action_pool > 0 else self.total
+        self.actions = torch.empty((pool, b, self.n_agents), dtype=torch.int32, device=dev)
         if self.n_agents == self.n and c:
-            self.actions[:, :, :c] = torch.randint(0, r * pc, (self.total, b, c), generator=g, device=dev, dtype=torch.int32)
+            self.actions[:, :, :c] = torch.randint(0, r * pc, (pool, b, c), generator=g, device=dev, dtype=torch.int32)
         if p:
-            self.actions[:, :, self.n_agents - p:] = torch.randint(0, r * pd, (self.total, b, p), generator=g, device=dev, dtype=torch.int32)
+            self.actions[:, :, self.n_agents - p:] = torch.randint(0, r * pd, (pool, b, p), generator=g, device=dev, dtype=torch.int32)
         # An event pair around ONE launch adds about 3-6 us to what it measures (tools/probes/launch_floor.hip) and costs host
         # time per step: irrelevant beside the 3.7 ms obs kernel, 10-30 % of a 17-40 us step.  So: two kernels per step with
         # the expansion dominant (LinearObs, N > 128) -> per-launch events inside the timed region.  One kernel per step
@@ -418,7 +420,7 @@ class Session:
             new_episode = with_reset and k % 10 == 0
             if new_episode:                              # EPISODE_LENGTH = 10 (d2d_env.py:16): new layout per episode
                 h.reset_positions(1234, k // 10)
-            step(actions[k])
+            step(actions[k % self.pool])
             planes = getattr(self, 'planes_gather', None)
             if gatherer is not None and (new_episode or k == 0):
                 # position columns only change at reset (not per step); planes plan: the library's own link rows
@@ -457,7 +459,7 @@ class Session:
                 k1 = min(k0 + GROUP, self.total)
                 e0.record(stream)
                 for k in range(k0, k1):
-                    h.step(self.actions[k].data_ptr())
+                    h.step(self.actions[k % self.pool].data_ptr())
                 e1.record(stream)
                 pairs.append((e0, e1, k1 - k0))
             torch.cuda.synchronize(self.dev)
@@ -514,7 +516,7 @@ class Session:
         """Wall time per VecD2DEnv.step - the PUBLIC batched API (obs, rewards, dones, info out), fresh actions every step,
         nothing synchronised inside the loop - beside the bare C-ABI handle loop over the same steps."""
         torch, env, h = self.torch, self.env, self.h
-        acts = [self.actions[k % self.total] for k in range(steps)]
+        acts = [self.actions[k % self.pool] for k in range(steps)]
         out = {}
         for name, fn in (('vec_env_step', lambda a: env.step(a)), ('handle_step', lambda a: h.step(a.data_ptr()))):
             for a in acts[:10]:
@@ -611,7 +613,8 @@ def worker(args):
             torch.cuda.synchronize(dev)
 
     sess = Session(torch, args, args.workload, args.obs, dev, rank, local, args.steps, args.warmup, envs=args.envs,
-                   cue_mode=args.cue_actions, tune=args.tune, stub=stub, export=not args.no_export)
+                   cue_mode=args.cue_actions, tune=args.tune, stub=stub, export=not args.no_export,
+                   action_pool=128 if args.steps + args.warmup > 128 else 0)      # long runs: 128 action tensors (1 GB at 4096 x 512) round-robin
     b, n = sess.b, sess.n
 
     def make_gatherer(mode, signal_every=1):
@@ -702,8 +705,8 @@ def worker(args):
         if extras.get('box_write_ceiling'):
             roof['box_ceiling_GBs'] = extras['box_write_ceiling']['GBps']
             roof['frac_of_box_ceiling'] = roof['achieved'] / roof['box_ceiling_GBs'] if roof['kernel'] == 'obs_expand_kernel' else None
-            roof['box_ceiling_note'] = ('the best pure-store kernel this library could build on this box (box_write_ceiling); above 1 the obs '
-                                        'kernel out-writes every fill variant tried')
+            roof['box_ceiling_note'] = ('the best store-only kernel this library could build on this box (box_write_ceiling: plain fills in 32 geometries, '
+                                        'hipMemsetAsync, and fills with the obs kernel\'s load + barrier structure and scope-bit stores)')
         cfg = sess.config(world, (f' + per-step all-gather ({args.gather}: rewards' + (', (sinr, snr) columns of the obs table'
                                   + (f' every {args.signal_every} steps' if args.signal_every > 1 else '') if args.gather == 'table' else '')
                                   + '; position columns once per episode)') if gatherer else '')
@@ -828,9 +831,12 @@ def n1_extras(torch, args, dev, local, fence):
     the device-side reset, each with its own roofline block; the public VecD2DEnv.step against the bare handle loop; the
     box's write ceiling."""
     out = {'other_workloads': {}, 'vec_env_step_ms': {}}
-    # BASELINE.json configs[1]: 1024 x 50, traffic-model CUEs, LinearObs fused into the step launch
-    s = Session(torch, args, 'default', 'linear', dev, 0, local, 200, 20)
-    out['other_workloads']['default'] = summarise(s, s.timed(fence), 200)
+    # BASELINE.json configs[1]: 1024 x 50, traffic-model CUEs, LinearObs fused into the step launch.  2000 + 2000 steps (60 ms):
+    # behind an idle stretch (closing one session and building the next is host work) the chip needs about 1000 of these
+    # 14 us steps (15 ms) to come back to its busy clocks and runs 5 - 10 % slower until then (tools/probes/clock_state.py,
+    # profiles/r4_clock_state_default.jsonl) - a 220-step run measured the ramp, not the kernel
+    s = Session(torch, args, 'default', 'linear', dev, 0, local, 2000, 2000, action_pool=256)
+    out['other_workloads']['default'] = summarise(s, s.timed(fence), 2000)
     try:                                                  # what a pure fill of about the same size reaches on this box (61 MB of obs per step)
         small, _ = s.h.probe_write_variants(64 << 20, 20)
         out['other_workloads']['default']['roofline']['box_ceiling_GBs_64MiB_bursts'] = small
@@ -839,8 +845,8 @@ def n1_extras(torch, args, dev, local, fence):
     out['vec_env_step_ms']['default (config 2), LinearObs'] = s.vec_env_step_ms()
     s.close()
     # BASELINE.json configs[3]: FreeSpacePathLoss + a custom ObsFunction through the plugin ABI, 4096 x 512
-    s = Session(torch, args, 'plugin', 'table', dev, 0, local, 200, 20)
-    out['other_workloads']['plugin'] = summarise(s, s.timed(fence), 200)
+    s = Session(torch, args, 'plugin', 'table', dev, 0, local, 1000, 1000, action_pool=64)      # 58 ms: as above
+    out['other_workloads']['plugin'] = summarise(s, s.timed(fence), 1000)
     out['vec_env_step_ms']['stress sizes, compact obs (OwnLinkObsFunction)'] = s.vec_env_step_ms()
     s.close()
     # the stress workload as EPISODES: positions redrawn on the device every 10 steps (d2d_env.py:16,45-52), 3 episodes
@@ -854,10 +860,25 @@ def n1_extras(torch, args, dev, local, fence):
         blocks, rows = (768, 1024, 512, 256), (2, 4, 8, 32)
         k = max(range(len(rates)), key=lambda v: rates[v])
         name = 'hipMemsetAsync' if k == 32 else f'{blocks[k & 3]} threads x {rows[(k >> 2) & 3]} rows per workgroup, ' + ('plain' if k & 16 else 'nontemporal') + ' stores'
+        # ... and the forms round 4 found faster than every plain fill: the obs kernel's own TIMING structure (every workgroup
+        # stages a table row through LDS behind a barrier before it stores) and the gfx942+ scope bits on the stores
+        staged = {}
+        for label, variant in (('1024 threads x 2 rows, LDS stage + barrier, sc1 nt stores', 1 + 32 + 512),
+                               ('1024 threads x 2 rows, LDS stage + barrier, sc0 sc1 nt stores', 1 + 32 + 384),
+                               ('1024 threads x 2 rows, LDS stage + barrier, nt stores', 1 + 32),
+                               ('768 threads x 2 rows (the obs kernel geometry), LDS stage + barrier, sc1 nt stores', 0 + 32 + 512),
+                               ('768 threads x 2 rows (the obs kernel geometry), LDS stage + barrier, nt stores', 0 + 32)):
+            staged[label] = max(s.h.probe_write_staged(8 << 30, variant, 0, iters=5) for _ in range(2))
+        kb = max(staged, key=staged.get)
+        if staged[kb] > best:
+            best, name = staged[kb], kb
         out['box_write_ceiling'] = {'GBps': best, 'best_variant': name, 'obs_kernel_geometry_GBps': rates[0], 'hipMemsetAsync_GBps': rates[32],
+                                    'best_plain_fill_GBps': max(rates[:32]), 'staged_forms_GBps': staged,
                                     'what': 'd2d_probe_write_variants: 8 GiB written 5 times by each of 32 pure fill kernels (block 768 / 1024 / 512 / 256 '
                                             'threads x 2 / 4 / 8 / 32 rows per workgroup x nontemporal / plain 16-byte stores, XCD-grouped dispatch '
-                                            'order; the first is the obs kernel\'s own geometry) and by hipMemsetAsync; GBps = the best of them'}
+                                            'order; the first is the obs kernel\'s own geometry), by hipMemsetAsync, and by the staged forms of '
+                                            'd2d_probe_write_staged (a table row through LDS behind a barrier before the stores; sc1 / sc0 sc1 scope bits '
+                                            'with nt); GBps = the best of them'}
     except Exception as exc:                              # pragma: no cover - a probe failure must not lose the line
         out['box_write_ceiling'] = {'error': repr(exc)}
     s.close()

@@ -89,8 +89,6 @@ SIGNATURES = {
     'd2d_set_tuning': (C.c_int, [_P, _I, _I]),
     'd2d_get_buffer': (C.c_int, [_P, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     'd2d_bind_buffer': (C.c_int, [_P, _I, _P, C.c_size_t]),
-    'd2d_block_alloc': (C.c_int, [_I, C.c_size_t, C.POINTER(_P)]),
-    'd2d_block_free': (C.c_int, [_I, _P]),
     'd2d_upload': (C.c_int, [_P, _I, _P, C.c_size_t, C.c_size_t]),
     'd2d_download': (C.c_int, [_P, _I, _P, C.c_size_t, C.c_size_t]),
     'd2d_set_positions': (C.c_int, [_P, _FP, _FP, _I, _I]),
@@ -142,34 +140,6 @@ def _check(rc: int) -> None:
 
 def _dptr(a: np.ndarray):
     return a.ctypes.data_as(_DP)
-
-
-class DeviceBlock:
-    """A device allocation of its own (d2d_block_alloc: one hipMalloc, never a piece of a caching allocator's block), alive
-    as long as this object is.  Exposes __cuda_array_interface__, so `torch.as_tensor(block, device=...)` is a zero-copy
-    tensor that keeps the block alive (torch holds a reference to the exporting object)."""
-
-    def __init__(self, device_ordinal: int, shape, typestr: str = '<f4') -> None:
-        self._lib = load_library()
-        self.device_ordinal = int(device_ordinal)
-        self.shape = tuple(int(d) for d in shape)
-        n = 1
-        for d in self.shape:
-            n *= d
-        self.nbytes = n * int(typestr[-1])
-        ptr = _P()
-        _check(self._lib.d2d_block_alloc(self.device_ordinal, max(self.nbytes, 1), C.byref(ptr)))
-        self.ptr = ptr.value
-        self.__cuda_array_interface__ = {'shape': self.shape, 'typestr': typestr, 'data': (self.ptr, False), 'version': 2,
-                                         'strides': None}
-
-    def __del__(self):
-        ptr, self.ptr = getattr(self, 'ptr', None), None
-        if ptr:
-            try:
-                self._lib.d2d_block_free(self.device_ordinal, _P(ptr))
-            except Exception:
-                pass
 
 
 class Handle:

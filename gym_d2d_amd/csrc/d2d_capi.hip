@@ -859,7 +859,10 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
     USE_DEVICE(h);
     switch (key) {
         case D2D_TUNE_OBS_ROWS_PER_WG: h->tune_rows = value; break;
-        case D2D_TUNE_OBS_NONTEMPORAL: h->tune_nt = value ? 1 : 0; break;
+        case D2D_TUNE_OBS_NONTEMPORAL:
+            if (value < 0 || value > 5) return fail(D2D_ERR_INVALID, "obs store policy must be in [0, 5]");
+            h->tune_nt = value;
+            break;
         case D2D_TUNE_OBS_XCD_REMAP: h->tune_xcd = value < 0 ? 0 : value; break;
         case D2D_TUNE_OBS_VARIANT: h->tune_variant = value; break;
         case D2D_TUNE_OBS_STAGGER:
@@ -961,29 +964,6 @@ int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
         h->have_pos = h->buf[D2D_BUF_POS_X].ptr && h->buf[D2D_BUF_POS_Y].ptr;
         h->lpos_dirty = true;
     }
-    return D2D_OK;
-}
-
-int d2d_block_alloc(int32_t device_ordinal, size_t bytes, void** dev_ptr) {
-    if (!dev_ptr || bytes == 0) return fail(D2D_ERR_INVALID, "bad argument");
-    *dev_ptr = nullptr;
-    int count = 0;
-    HIP_TRY(hipGetDeviceCount(&count));
-    if (device_ordinal < 0 || device_ordinal >= count) return fail(D2D_ERR_HIP, "device_ordinal out of range (no usable GPU?)");
-    DeviceGuard guard(device_ordinal);
-    if (guard.err != hipSuccess) return fail(D2D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
-    HIP_TRY(hipMalloc(dev_ptr, bytes));
-    return D2D_OK;
-}
-
-int d2d_block_free(int32_t device_ordinal, void* dev_ptr) {
-    if (!dev_ptr) return D2D_OK;
-    int count = 0;
-    HIP_TRY(hipGetDeviceCount(&count));
-    if (device_ordinal < 0 || device_ordinal >= count) return fail(D2D_ERR_HIP, "device_ordinal out of range (no usable GPU?)");
-    DeviceGuard guard(device_ordinal);
-    if (guard.err != hipSuccess) return fail(D2D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
-    HIP_TRY(hipFree(dev_ptr));                      // synchronises with the work that may still use the block
     return D2D_OK;
 }
 
@@ -1295,8 +1275,8 @@ int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double*
         if (v < n) per_variant[v] = rate;
         if (rate > best) best = rate;
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(tmp);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(tmp);
     if (rc) return rc;
     *best_gb_per_s = best;
     return D2D_OK;
@@ -1304,7 +1284,7 @@ int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double*
 
 int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters, double* gb_per_s) {
     if (!h || !gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
-    if (variant < 0 || variant >= 4 * d2d::fill_variants()) return fail(D2D_ERR_INVALID, "variant must be in [0, 128)");
+    if (variant < 0 || variant >= 5 * 4 * d2d::fill_variants()) return fail(D2D_ERR_INVALID, "variant must be in [0, 640)");
     if (stagger < 0 || stagger > 64) return fail(D2D_ERR_INVALID, "stagger must be in [0, 64]");
     const size_t group = (size_t)8 * 512 * 1024 * 16;
     if (bytes < group) return fail(D2D_ERR_INVALID, "the probe needs at least 64 MiB");
@@ -1320,9 +1300,9 @@ int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t v
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     const int rc = time_fill(h, tmp, bytes, src, variant, stagger, iters, e0, e1, gb_per_s);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(src);
-    if (!dst_dev) hipFree(tmp);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(src);
+    if (!dst_dev) (void)hipFree(tmp);
     return rc;
 }
 

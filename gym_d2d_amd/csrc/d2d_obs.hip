@@ -21,13 +21,29 @@ namespace d2d {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// One 16-byte store under a chosen cache policy (gfx942+ scope / streaming bits of the global_store encoding): 0 plain, 1 nt
+// (what __builtin_nontemporal_store emits), 2 sc1 (agent scope), 3 sc0 sc1 (system scope: written through), 4 sc0 sc1 nt, 5 sc1 nt.
+// The obs stream is written once and never read by the GPU again; which policy drains it fastest is measured, not assumed
+// (d2d_probe_write_staged, D2D_TUNE_OBS_NONTEMPORAL).
+template <int POLICY>
+__device__ __forceinline__ void store16(f32x4* p, f32x4 v) {
+    if (POLICY == 0) *p = v;
+    else if (POLICY == 1) __builtin_nontemporal_store(v, p);
+    // (no "memory" clobber: nothing in these kernels reads what they store, and a clobber would pin every LDS read of the next
+    // row behind the store of this one - the obs kernel with the clobber lost 13 % where the fill, which has no reads, gained 5 %)
+    else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v));
+    else if (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v));
+    else if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v));
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v));
+}
+
 // source float index inside T_flat for output column f (even) of row i
 __device__ __forceinline__ unsigned src_col(unsigned f, unsigned i) {
     const unsigned head = 6u * i;
     return f < 6u ? head + f : (f < head + 6u ? f - 6u : f);
 }
 
-template <int VEC, bool NT>
+template <int VEC, int NT>           // NT: the store policy of store16 (0 plain, 1 nt, 2 .. 5 scope variants; VEC == 2: 0 / 1 only)
 __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     extern __shared__ __align__(16) float t_flat[];          // [6N]
     const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
@@ -72,16 +88,23 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
         const bool own0 = f0 < 6u, own1 = f1 < 6u;
         f32x4* o4 = reinterpret_cast<f32x4*>(out) + tid;
         const f32x2* t2 = reinterpret_cast<const f32x2*>(t_flat);
-#pragma unroll 2
-        for (unsigned i = r0; i < r1; ++i) {
+        const auto row = [&](unsigned i) {
             const unsigned head = 6u * i;
             const unsigned s0 = own0 ? head + f0 : (i >= t0 ? f0 - 6u : f0);
             const unsigned s1 = own1 ? head + f1 : (i >= t1 ? f1 - 6u : f1);
             const f32x2 lo = t2[s0 >> 1], hi = t2[s1 >> 1];
             const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
-            f32x4* p = o4 + (size_t)(i - r0) * T;
-            if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+            return v;
+        };
+        // rows in pairs, all four LDS reads ahead of the two stores (written out: the scope-policy stores are asm statements,
+        // which the unroller leaves alone)
+        unsigned i = r0;
+        for (; i + 1u < r1; i += 2u) {
+            const f32x4 va = row(i), vb = row(i + 1u);
+            store16<NT>(o4 + (size_t)(i - r0) * T, va);
+            store16<NT>(o4 + (size_t)(i + 1u - r0) * T, vb);
         }
+        if (i < r1) store16<NT>(o4 + (size_t)(i - r0) * T, row(i));
         return;
     }
 #pragma unroll 4
@@ -94,8 +117,7 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
             const f32x2 lo = reinterpret_cast<const f32x2*>(t_flat)[src_col(f, i) >> 1];      // even index: one ds_read_b64
             const f32x2 hi = reinterpret_cast<const f32x2*>(t_flat)[src_col(f + 2u, i) >> 1];
             const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
-            f32x4* p = reinterpret_cast<f32x4*>(out + (size_t)idx * 4);
-            if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+            store16<NT>(reinterpret_cast<f32x4*>(out + (size_t)idx * 4), v);
         } else {
             const f32x2 v = reinterpret_cast<const f32x2*>(t_flat)[src_col(f, i) >> 1];      // even index: one ds_read_b64
             f32x2* p = reinterpret_cast<f32x2*>(out + (size_t)idx * 2);
@@ -194,11 +216,17 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
         return hipGetLastError();
     }
     if (a.vec == 4) {
-        if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<4, true>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((obs_expand_kernel<4, false>), grid, block, lds, stream, a);
+        switch (a.nontemporal) {
+            case 0: hipLaunchKernelGGL((obs_expand_kernel<4, 0>), grid, block, lds, stream, a); break;
+            case 2: hipLaunchKernelGGL((obs_expand_kernel<4, 2>), grid, block, lds, stream, a); break;
+            case 3: hipLaunchKernelGGL((obs_expand_kernel<4, 3>), grid, block, lds, stream, a); break;
+            case 4: hipLaunchKernelGGL((obs_expand_kernel<4, 4>), grid, block, lds, stream, a); break;
+            case 5: hipLaunchKernelGGL((obs_expand_kernel<4, 5>), grid, block, lds, stream, a); break;
+            default: hipLaunchKernelGGL((obs_expand_kernel<4, 1>), grid, block, lds, stream, a); break;
+        }
     } else {
-        if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<2, true>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((obs_expand_kernel<2, false>), grid, block, lds, stream, a);
+        if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<2, 1>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((obs_expand_kernel<2, 0>), grid, block, lds, stream, a);
     }
     return hipGetLastError();
 }
@@ -211,7 +239,7 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
 // (T float4, 12 KiB at 768 threads) from `src` into LDS behind a barrier and stores what it reads back from LDS; bit 1 - wave w of
 // the workgroup sleeps w * stagger x 64 clocks before its first store.  (Does the obs kernel out-write its own geometry run as
 // a plain fill - 7.19 vs 6.39 TB/s in round 3 - because its load + barrier phase spreads the waves' stores in time?)
-template <bool NT, int STAGE>
+template <int POLICY, int STAGE>
 __global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, const f32x4* src, unsigned chunks, unsigned rows_per_wg, unsigned rows_per_env, int xcd,
                                                     float value, int stagger) {
     extern __shared__ __align__(16) float fill_lds[];
@@ -236,14 +264,13 @@ __global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, const f32x4* src
     }
     f32x4* o4 = dst + ((size_t)env * rows_per_env + (size_t)chunk * rows_per_wg) * T + threadIdx.x;
 #pragma unroll 2
-    for (unsigned i = 0; i < rows_per_wg; ++i) {
-        if (NT) __builtin_nontemporal_store(v, o4 + (size_t)i * T); else o4[(size_t)i * T] = v;
-    }
+    for (unsigned i = 0; i < rows_per_wg; ++i) store16<POLICY>(o4 + (size_t)i * T, v);
 }
 
 // Variant v of the family: block in {768, 1024, 512, 256} x rows per workgroup in {2, 4, 8, 32} x {nt, plain}, XCD-grouped
 // order; v == 0 is the obs kernel's geometry.  Bits 5-6 select the staged forms above (32: LDS stage + barrier, 64: per-wave
-// sleep stagger of `stagger` x 64 clocks, 96: both).  "Envs" are regions of 512 rows; n_float4 is rounded DOWN to whole
+// sleep stagger of `stagger` x 64 clocks, 96: both); v / 128 = 1 .. 4 replaces the store's cache policy by sc1, sc0 sc1,
+// sc0 sc1 nt, sc1 nt (store16).  "Envs" are regions of 512 rows; n_float4 is rounded DOWN to whole
 // groups of 8 regions; returns the float4 actually written through *written.
 int fill_variants() { return 4 * 4 * 2; }
 
@@ -252,6 +279,7 @@ hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t str
     const unsigned T = blocks[variant & 3], rows_per_wg = rows[(variant >> 2) & 3], rows_per_env = 512, chunks = rows_per_env / rows_per_wg;
     const bool nt = ((variant >> 4) & 1) == 0;
     const int stage = (variant >> 5) & 3;
+    const int policy = (variant >> 7) > 0 ? (variant >> 7) + 1 : (nt ? 1 : 0);
     const size_t env_f4 = (size_t)rows_per_env * T;
     const size_t envs = (n_float4 / env_f4) & ~(size_t)7;
     if (written) *written = envs * env_f4;
@@ -261,11 +289,14 @@ hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t str
     const size_t lds = (stage & 1) ? (size_t)T * 16 : 0;
     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-#define D2D_FILL(NTV, ST) hipLaunchKernelGGL((fill_kernel<NTV, ST>), grid, block, lds, stream, d4, s4, chunks, rows_per_wg, rows_per_env, 1, value, stagger)
-    switch ((nt ? 4 : 0) | stage) {
-        case 0: D2D_FILL(false, 0); break; case 1: D2D_FILL(false, 1); break; case 2: D2D_FILL(false, 2); break; case 3: D2D_FILL(false, 3); break;
-        case 4: D2D_FILL(true, 0); break; case 5: D2D_FILL(true, 1); break; case 6: D2D_FILL(true, 2); break; default: D2D_FILL(true, 3); break;
+#define D2D_FILL(P, ST) hipLaunchKernelGGL((fill_kernel<P, ST>), grid, block, lds, stream, d4, s4, chunks, rows_per_wg, rows_per_env, 1, value, stagger)
+#define D2D_FILL_P(P)                                                                                               \
+    switch (stage) { case 0: D2D_FILL(P, 0); break; case 1: D2D_FILL(P, 1); break; case 2: D2D_FILL(P, 2); break; default: D2D_FILL(P, 3); break; }
+    switch (policy) {
+        case 0: D2D_FILL_P(0); break; case 1: D2D_FILL_P(1); break; case 2: D2D_FILL_P(2); break;
+        case 3: D2D_FILL_P(3); break; case 4: D2D_FILL_P(4); break; default: D2D_FILL_P(5); break;
     }
+#undef D2D_FILL_P
 #undef D2D_FILL
     return hipGetLastError();
 }

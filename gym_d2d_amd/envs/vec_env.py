@@ -141,17 +141,10 @@ class VecD2DEnv:
         b, n, d = self.num_envs, self.num_links, h.num_devices
         cap = h.max_links
 
-        ordinal = dev.index if dev.index is not None else torch.cuda.current_device()
-        typestr = {torch.float32: '<f4', torch.float64: '<f8', torch.int32: '<i4'}
-
         def alloc(which, shape, dtype):
-            # Every buffer the kernels touch is a device allocation OF ITS OWN (d2d_block_alloc), not a torch.empty: as pieces
-            # of blocks that torch's caching allocator re-uses (a closed 26 GB env) the same launches ran 9 - 11 % slower
-            # (profiles/r4_context_*).  The tensors are zero copy and keep their block alive for as long as
-            # anybody holds them; capacity follows the handle's max_links so re-linking never outgrows the binding.
-            block = _native.DeviceBlock(ordinal, shape, typestr[dtype])
-            t = torch.as_tensor(block, device=dev)
-            h.bind_buffer(which, block.ptr, block.nbytes)
+            # capacity follows the handle's max_links so re-linking never outgrows the binding
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            h.bind_buffer(which, t.data_ptr(), t.numel() * t.element_size())
             return t
 
         self._t['pos_x'] = alloc(_native.BUF_POS_X, (b, d), torch.float32)

@@ -195,7 +195,8 @@ int d2d_set_export_actions(d2d_handle* h, int32_t enabled);
 /* Launch-geometry knobs (performance only, results do not change).                                 */
 typedef enum d2d_tuning {
     D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* obs rows written per workgroup; 0 = auto                       */
-    D2D_TUNE_OBS_NONTEMPORAL = 1,  /* 1 (default): nontemporal stores for the obs stream             */
+    D2D_TUNE_OBS_NONTEMPORAL = 1,  /* store policy of the obs stream: 1 (default) nontemporal, 0 plain; A/B: 2 sc1, 3 sc0 sc1,
+                                      4 sc0 sc1 nt, 5 sc1 nt (the scope bits of the gfx942+ store encoding)            */
     D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
     D2D_TUNE_OBS_BLOCK = 3,        /* threads per obs workgroup; 0 = auto                            */
     D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): T staged in LDS; 1: T read from global (A/B)      */
@@ -235,13 +236,6 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
 int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes);
 /* Use caller-owned device memory for a buffer (e.g. a torch tensor); never freed by the library.   */
 int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes);
-/* A device block that is an allocation OF ITS OWN (one hipMalloc, released by d2d_block_free) for a caller that binds
- * buffers.  Why the library offers this: the small workload's fused step ran 11 % slower whenever its 61 MB obs block
- * was a PIECE of a large allocation - a framework's caching allocator re-using a 26 GB block - than as a dedicated
- * allocation, with identical TLB and L2-channel counters (profiles/r4_context_*); a dedicated block makes
- * the step independent of what the process allocated before.  VecD2DEnv keeps D2D_BUF_OBS in one.                      */
-int d2d_block_alloc(int32_t device_ordinal, size_t bytes, void** dev_ptr);
-int d2d_block_free(int32_t device_ordinal, void* dev_ptr);
 /* Synchronous host<->device copies (ordered after queued work on the handle's stream).             */
 int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes, size_t dst_offset);
 int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset);
@@ -336,7 +330,8 @@ int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double*
 int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s);
 /* One member of the family with the obs kernel's TIMING structure added: variant = the geometry index above
  * + 32 (every workgroup first stages one row of a table through LDS behind a barrier and stores what it reads
- * back) + 64 (wave w sleeps w * stagger * 64 clocks before its first store).  dst_dev = NULL writes a scratch
+ * back) + 64 (wave w sleeps w * stagger * 64 clocks before its first store) + 128 * k (k = 1 .. 4: the store's cache
+ * policy sc1 / sc0 sc1 / sc0 sc1 nt / sc1 nt instead of nt or plain).  dst_dev = NULL writes a scratch
  * buffer of `bytes`; a device pointer writes THAT memory (e.g. the obs block itself: same pages, same
  * footprint as the kernel being explained).                                                              */
 int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters,

@@ -53,9 +53,6 @@ int main(void) {
     EXPECT_ERR(d2d_get_buffer(NULL, 0, &p, &n));
     EXPECT_ERR(d2d_bind_buffer(NULL, 0, NULL, 0));
     EXPECT_ERR(d2d_upload(NULL, 0, fone, 4, 0));
-    EXPECT_ERR(d2d_block_alloc(0, 0, &p));
-    EXPECT_ERR(d2d_block_alloc(0, 64, NULL));
-    EXPECT_ERR(d2d_block_alloc(-1, 64, &p));
     EXPECT_ERR(d2d_download(NULL, 0, fone, 4, 0));
     EXPECT_ERR(d2d_set_positions(NULL, fone, fone, 0, 1));
     EXPECT_ERR(d2d_reset_positions(NULL, 1, 0, mask, fone));

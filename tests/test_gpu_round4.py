@@ -311,7 +311,7 @@ def test_staged_write_probe(native):
     from gym_d2d_amd.simulator import Simulator
     sim = Simulator(dict(num_rbs=2, num_cues=2, num_due_pairs=2, num_envs=1))
     h = sim.handle
-    for variant, stagger in ((0, 0), (32, 0), (64, 2), (96, 1), (32 + 1, 0)):
+    for variant, stagger in ((0, 0), (32, 0), (64, 2), (96, 1), (32 + 1, 0), (128, 0), (256 + 32, 0), (384, 0), (512 + 1, 0)):
         assert h.probe_write_staged(64 << 20, variant, stagger, iters=2) > 100.0
     import torch
     dst = torch.zeros(64 << 18, dtype=torch.float32, device='cuda')       # 64 MiB
@@ -319,7 +319,7 @@ def test_staged_write_probe(native):
     with pytest.raises(native.NativeError):
         h.probe_write_staged(1 << 20, 0)
     with pytest.raises(native.NativeError):
-        h.probe_write_staged(64 << 20, 128)
+        h.probe_write_staged(64 << 20, 640)
     sim.handle.close()
 
 

@@ -13,6 +13,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -98,7 +99,7 @@ def main():
     rec = {'command': 'tools/profile_bench.sh: rocprofv3 --pmc <one counter set per pass> --output-format csv -- python3 bench.py '
                       f'--workload {wl} --obs {obs} --no-cpu-baseline --no-single-env-latency --no-extras {extra} --steps 5 --warmup 1'.replace('  ', ' '),
            'workload_key': f'{wl}/{key_obs}', 'source_digest': source_digest(), 'kernels': kernels,
-           'kernel_trace_durations': durations(raw, 12)}
+           'kernel_trace_durations': durations(raw, int(os.environ.get('PROFILE_WARMUP', '10')) + 2)}
     out = ROOT / 'profiles' / f'{tag}_pmc_{wl}_{obs}{suffix}.json'
     out.write_text(json.dumps(rec, indent=1))
     if (wl, obs) == ('stress', 'table') and suffix == '':
