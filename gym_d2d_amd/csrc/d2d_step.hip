@@ -37,7 +37,13 @@
 //   * all arithmetic is in the LINEAR domain (mW): sinr = S / (I + N) with one 10*log10 at the end; the literal
 //     dB-domain transcription cannot hold 1e-5 relative in fp32 (hard parts);
 //   * the capacity sum is a DPP wave reduction + an order-independent cross-wave sum (32.32 fixed point in the barrier-free
-//     epilogue of the one-env-per-workgroup kernels, a fixed-order float sum elsewhere): run-to-run deterministic.
+//     epilogue of the one-env-per-workgroup kernels, a fixed-order float sum elsewhere): run-to-run deterministic;
+//   * small envs (N <= 128) expand their LinearObs block inside this launch: the workgroup's envs are one contiguous region,
+//     walked in passes of blockDim consecutive float4 with a per-lane (env, row, column) position that is advanced, not
+//     recomputed, and the LDS reads of the next pass issued ahead of the store of this one (round 4: 15.7 -> 13.4 us at
+//     1024 x 50 on one box, profiles/r4_ab_builds_default_r2head_r3head_r4.jsonl);
+//   * what a learner does not read is not written: D2D_OBS_NONE (no table), D2D_REWARD_PER_ENV (SystemCapacity's scalar once per
+//     env), d2d_set_export_actions(0) (no decoded rb / pwr planes) take the rollout kernel from 64 + 8 to 36 bytes per link.
 #include "d2d_internal.h"
 #include <type_traits>
 

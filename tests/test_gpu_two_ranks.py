@@ -74,6 +74,23 @@ def _rank(rank, world, port, out_dir):
     block, _ = g4.wait()
     torch.cuda.synchronize()
     assert g4.reward_step == 0 and np.array_equal(block.cpu().numpy(), np.stack([outs[k][0] for k in range(STEPS)]))
+    # the learner configuration: every rank runs D2D_OBS_NONE with the per-env reward and no decoded planes;
+    # the planes plan gathers the (sinr, snr) planes and the library's link-position rows - the same global table, bit for bit
+    from gym_d2d_amd.envs.obs_fn import SignalPlanesObsFunction
+    lean = VecD2DEnv(dict(CFG, obs_fn=SignalPlanesObsFunction), num_envs=end - first, first_env=first, export_actions=False,
+                     reward_per_env=True)
+    lean.reset(seed=99)
+    g5 = StepGatherer(end - first, 14, dev, mode='planes')
+    g5.gather_positions(lean.link_positions())
+    for k in range(STEPS):
+        (sinr, snr), rew_env, _, _ = lean.step(torch.as_tensor(_actions(k, first, end - first), device=dev))
+        g5.launch(rew_env, sinr=sinr, snr=snr)
+        r5, planes = g5.wait()
+        t5 = g5.table()
+        torch.cuda.synchronize()
+        assert np.array_equal(r5.cpu().numpy(), outs[k][0]) and np.array_equal(t5.cpu().numpy(), outs[k][1]), k
+        assert tuple(planes[0].shape) == (B_GLOBAL, 14)
+    lean.close()
     if rank == 0:
         np.savez(Path(out_dir) / 'gathered.npz', **{f'{name}{k}': arr for k, o in enumerate(outs)
                                                     for name, arr in zip(('reward', 'table', 'obs'), o)})
