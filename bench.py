@@ -837,6 +837,9 @@ def n1_extras(torch, args, dev, local, fence):
     # profiles/r4_clock_state_default.jsonl) - a 220-step run measured the ramp, not the kernel
     s = Session(torch, args, 'default', 'linear', dev, 0, local, 2000, 2000, action_pool=256)
     out['other_workloads']['default'] = summarise(s, s.timed(fence), 2000)
+    # where a 61 MB obs block lands decides its speed class (13.2 / 13.9 / 15.1 us per step, profiles/r4_obs_block_placement_candidates.jsonl):
+    # VecD2DEnv timed 6 candidate blocks at its first reset and kept the fastest - what it saw is part of the record
+    out['other_workloads']['default']['obs_block_placement_trials'] = getattr(s.env, 'placement', None)
     try:                                                  # what a pure fill of about the same size reaches on this box (61 MB of obs per step)
         small, _ = s.h.probe_write_variants(64 << 20, 20)
         out['other_workloads']['default']['roofline']['box_ceiling_GBs_64MiB_bursts'] = small

@@ -39,7 +39,7 @@ _OUTPUTS = (('sinr_db', _native.BUF_SINR_DB), ('snr_db', _native.BUF_SNR_DB), ('
 class VecD2DEnv:
     def __init__(self, env_config: Optional[dict] = None, num_envs: Optional[int] = None, *,
                  cue_actions: str = 'agent', use_torch: Optional[bool] = None, first_env: int = 0,
-                 export_actions: bool = True, reward_per_env: bool = False) -> None:
+                 export_actions: bool = True, reward_per_env: bool = False, placement_trials='auto') -> None:
         """cue_actions: 'agent' - step() takes actions for CUEs and DUEs [B, C+P] (reference behaviour);
         'traffic' - CUE links follow the env's traffic model (round-robin RB at max power,
         traffic_model.py:15-22): their (rb, pwr) are constants of the kernel's link records
@@ -55,6 +55,14 @@ class VecD2DEnv:
         reward_per_env: True - SystemCapacityRewardFunction's reward is ONE scalar per env handed to every agent
         (reward_fn.py:42-44); step() then returns it as [B] instead of N copies [B, N] (d2d_set_reward_layout: 4 bytes per
         link and step less).  Only with the native SystemCapacity reward.
+
+        placement_trials: where a SMALL obs block sits physically decides how fast the fused step streams it - the same 61 MB
+        block of BASELINE config 2 runs 13.2, 13.9 or 15.1 us per step depending on the allocation it landed in, reproducibly
+        per allocation and independent of every other buffer (profiles/r4_obs_block_placement_candidates.jsonl; TLB and
+        L2-channel counters equal, so it is how the block's pages spread over the memory channels).  K > 0: the first reset()
+        allocates K candidate obs blocks, times a few hundred steps on each and keeps the fastest (about 40 ms once per env).
+        'auto' = 6 for the fused LinearObs step with an obs block of 8 ... 256 MB (larger blocks average the effect out: the
+        25.8 GB block of config 3 is one speed everywhere), else 0.
 
         step()'s `dones` on the torch path is one of two preallocated CONSTANT tensors (all False / all True), shared by
         every call: treat it as read-only (clone it before an in-place update).
@@ -132,6 +140,12 @@ class VecD2DEnv:
         self.num_steps = 0
         self._episode = 0
         self._seed = cfg.seed if cfg.seed is not None else 0
+        obs_bytes = self.num_envs * self.num_links * 6 * self.num_links * (8 if getattr(self, '_native_obs64', False) else 4)
+        if placement_trials == 'auto':
+            fused = self.obs_fn.native_mode == _native.OBS_LINEAR and self.num_links <= 128 and not getattr(self, '_native_obs64', False)
+            placement_trials = 6 if (self.use_torch and fused and (8 << 20) <= obs_bytes <= (256 << 20)) else 0
+        self._placement_trials = int(placement_trials) if self.use_torch and self.obs_fn.native_mode == _native.OBS_LINEAR else 0
+        self.placement = None                      # after the trials: {'us_per_step': [...], 'chosen': k}
 
     # ------------------------------------------------------------------ buffers
     def _bind_torch_buffers(self) -> None:
@@ -238,7 +252,41 @@ class VecD2DEnv:
         self._episode += 1
         if self.simulator.handle.status_flags() & _native.FLAG_ZERO_DISTANCE:
             raise ValueError('math domain error')            # log10(0) in path_loss.py:66
+        if self._placement_trials > 1 and self.placement is None:
+            self._choose_obs_placement(self._placement_trials)
         return self._observe(self._view())
+
+    def _choose_obs_placement(self, trials: int, warm: int = 1000, steps: int = 256) -> None:
+        """Time the step on `trials` candidate obs blocks (all held at once, hence distinct physical ranges), keep the fastest.
+        The step repeated here is the reset's own (same positions, same actions in the bound action buffer: same outputs), so
+        the env's state after the trials is what reset() produced; only the shadowing model's step counter would advance, so
+        that model keeps the block it has."""
+        import time
+        h = self.simulator.handle
+        if getattr(self.simulator, 'shadowing_seed', None) is not None:
+            self.placement = {'skipped': 'ShadowingPathLoss draws per step'}
+            return
+        first = self._t['obs']
+        cands = [first] + [torch.empty_like(first) for _ in range(trials - 1)]
+        for _ in range(warm):                                   # past the clock ramp behind the idle stretch of building the env
+            h.step()
+        times = []
+        for c in cands:
+            h.bind_buffer(_native.BUF_OBS, c.data_ptr(), c.numel() * c.element_size())
+            for _ in range(32):
+                h.step()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                h.step()
+            torch.cuda.synchronize(self.device)
+            times.append((time.perf_counter() - t0) / steps * 1e6)
+        best = min(range(len(cands)), key=times.__getitem__)
+        self._t['obs'] = cands[best]
+        h.bind_buffer(_native.BUF_OBS, cands[best].data_ptr(), cands[best].numel() * cands[best].element_size())
+        h.step()                                                # the reset's step once more, into the block that stays
+        self._view_cache = None
+        self.placement = {'us_per_step': [round(t, 2) for t in times], 'chosen': best}
 
     def step(self, actions):
         """actions: int [B, num_agents] (torch CUDA tensor, or NumPy).  Returns (obs, rewards[B,N], dones[B], info).

@@ -403,3 +403,28 @@ def test_rollout_kernel_serves_the_obs_less_mode(native):
             w = outs[0][k][n]
             assert torch.equal(v.view(torch.int32) if v.is_floating_point() else v, w.view(torch.int32) if w.is_floating_point() else w), (k, n)
     assert tuple(outs[-1][0]['rew'].shape) == (B,)
+
+
+def test_obs_block_placement_trials(native):
+    """VecD2DEnv(placement_trials=K): the first reset() times K candidate obs blocks and keeps the fastest; the observation
+    it returns, and every later step, are bit-identical to an env that took the first block."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    cfg = {'num_rbs': 25, 'num_cues': 25, 'num_due_pairs': 25}
+    plain = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic', placement_trials=0)
+    tuned = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic', placement_trials=3)
+    auto = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic')
+    o0, o1 = plain.reset(seed=4), tuned.reset(seed=4)
+    assert plain.placement is None and auto._placement_trials == 6            # 15 MB obs block, fused step: inside 'auto'
+    assert len(tuned.placement['us_per_step']) == 3 and 0 <= tuned.placement['chosen'] < 3
+    assert torch.equal(o0, o1) and o1.data_ptr() == tuned._t['obs'].data_ptr()
+    for k in range(3):
+        act = torch.randint(0, 25 * 21, (256, 25), device=plain.device, dtype=torch.int32)
+        a, b = plain.step(act), tuned.step(act)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    o0, o1 = plain.reset(), tuned.reset()                                      # trials run once per env
+    assert torch.equal(o0, o1) and len(tuned.placement['us_per_step']) == 3
+    big = VecD2DEnv({'num_rbs': 64, 'num_cues': 100, 'num_due_pairs': 100}, num_envs=4)
+    assert big._placement_trials == 0                                          # two launches per step: not the fused small-N case
+    for e in (plain, tuned, auto, big):
+        e.close()
