@@ -56,13 +56,16 @@ class VecD2DEnv:
         (reward_fn.py:42-44); step() then returns it as [B] instead of N copies [B, N] (d2d_set_reward_layout: 4 bytes per
         link and step less).  Only with the native SystemCapacity reward.
 
-        placement_trials: where a SMALL obs block sits physically decides how fast the fused step streams it - the same 61 MB
-        block of BASELINE config 2 runs 13.2, 13.9 or 15.1 us per step depending on the allocation it landed in, reproducibly
-        per allocation and independent of every other buffer (profiles/r4_obs_block_placement_candidates.jsonl; TLB and
-        L2-channel counters equal, so it is how the block's pages spread over the memory channels).  K > 0: the first reset()
-        allocates K candidate obs blocks, times a few hundred steps on each and keeps the fastest (about 40 ms once per env).
-        'auto' = 6 for the fused LinearObs step with an obs block of 8 ... 256 MB (larger blocks average the effect out: the
-        25.8 GB block of config 3 is one speed everywhere), else 0.
+        placement_trials: where the step's dominant output block sits physically decides how fast the kernel streams it - the
+        same 61 MB obs block of BASELINE config 2 runs 13.2, 13.9 or 15.1 us per step depending on the allocation it landed in,
+        and the 50 MB table of the compact-obs step at 4096 x 512 26.7 or 28.1 us, reproducibly per allocation and independent of
+        every other buffer (profiles/r4_obs_block_placement_candidates.jsonl, r4_output_placement_candidates_stress_table.jsonl;
+        TLB and L2-channel counters are equal, so it is how the block's pages spread over the memory channels).  K > 0: the
+        first reset() times a few hundred steps on up to K candidate blocks (allocated one by one behind paddings of varying
+        size - megabytes at first, GiBs from the seventh on - all held until the choice) and keeps the fastest; it stops early once a candidate is 7 % faster than the slowest
+        seen (a faster class has shown up).  About 5 ms per candidate at config 2, 8 ms at stress sizes, once per env.
+        'auto' = 15 for an obs block (fused LinearObs step) or a table (compact obs) of 8 ... 256 MB - larger blocks average the
+        effect out (the 25.8 GB block of config 3 is one speed everywhere) - else 0.
 
         step()'s `dones` on the torch path is one of two preallocated CONSTANT tensors (all False / all True), shared by
         every call: treat it as read-only (clone it before an in-place update).
@@ -140,12 +143,18 @@ class VecD2DEnv:
         self.num_steps = 0
         self._episode = 0
         self._seed = cfg.seed if cfg.seed is not None else 0
-        obs_bytes = self.num_envs * self.num_links * 6 * self.num_links * (8 if getattr(self, '_native_obs64', False) else 4)
+        # which block the trials move: the obs block of the fused LinearObs step, or the table of the compact-obs step
+        mode = self.obs_fn.native_mode
+        fused = mode == _native.OBS_LINEAR and self.num_links <= 128 and not getattr(self, '_native_obs64', False)
+        self._placement_target = ('obs', _native.BUF_OBS) if fused else (('table', _native.BUF_OBS_TABLE) if mode == _native.OBS_TABLE else None)
         if placement_trials == 'auto':
-            fused = self.obs_fn.native_mode == _native.OBS_LINEAR and self.num_links <= 128 and not getattr(self, '_native_obs64', False)
-            placement_trials = 6 if (self.use_torch and fused and (8 << 20) <= obs_bytes <= (256 << 20)) else 0
-        self._placement_trials = int(placement_trials) if self.use_torch and self.obs_fn.native_mode == _native.OBS_LINEAR else 0
-        self.placement = None                      # after the trials: {'us_per_step': [...], 'chosen': k}
+            nbytes = 0
+            if self.use_torch and self._placement_target is not None:
+                t = self._t[self._placement_target[0]]
+                nbytes = t.numel() * t.element_size()
+            placement_trials = 15 if (8 << 20) <= nbytes <= (256 << 20) else 0
+        self._placement_trials = int(placement_trials) if self.use_torch and self._placement_target is not None else 0
+        self.placement = None                      # after the trials: {'buffer': ..., 'us_per_step': [...], 'chosen': k}
 
     # ------------------------------------------------------------------ buffers
     def _bind_torch_buffers(self) -> None:
@@ -256,37 +265,56 @@ class VecD2DEnv:
             self._choose_obs_placement(self._placement_trials)
         return self._observe(self._view())
 
-    def _choose_obs_placement(self, trials: int, warm: int = 1000, steps: int = 256) -> None:
-        """Time the step on `trials` candidate obs blocks (all held at once, hence distinct physical ranges), keep the fastest.
-        The step repeated here is the reset's own (same positions, same actions in the bound action buffer: same outputs), so
-        the env's state after the trials is what reset() produced; only the shadowing model's step counter would advance, so
-        that model keeps the block it has."""
+    def _choose_obs_placement(self, trials: int, warm_ms: float = 15.0, steps: int = 256) -> None:
+        """Time the step on up to `trials` candidate blocks for the dominant output (all held until the choice, hence distinct
+        physical ranges), keep the fastest.  The step repeated here is the reset's own (same positions, same actions in the
+        bound action buffer: same outputs), so the env's state after the trials is what reset() produced; only the shadowing
+        model's step counter would advance, so that model keeps the block it has."""
         import time
         h = self.simulator.handle
         if getattr(self.simulator, 'shadowing_seed', None) is not None:
             self.placement = {'skipped': 'ShadowingPathLoss draws per step'}
             return
-        first = self._t['obs']
-        cands = [first] + [torch.empty_like(first) for _ in range(trials - 1)]
-        for _ in range(warm):                                   # past the clock ramp behind the idle stretch of building the env
-            h.step()
-        times = []
-        for c in cands:
-            h.bind_buffer(_native.BUF_OBS, c.data_ptr(), c.numel() * c.element_size())
-            for _ in range(32):
-                h.step()
+        key, which = self._placement_target
+        base = self._t[key]                                     # a view of the bound allocation (capacity may exceed the active part)
+        first = base._base if base._base is not None else base
+        nbytes = first.numel() * first.element_size()
+
+        def timed(n):
             torch.cuda.synchronize(self.device)
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for _ in range(n):
                 h.step()
             torch.cuda.synchronize(self.device)
-            times.append((time.perf_counter() - t0) / steps * 1e6)
-        best = min(range(len(cands)), key=times.__getitem__)
-        self._t['obs'] = cands[best]
-        h.bind_buffer(_native.BUF_OBS, cands[best].data_ptr(), cands[best].numel() * cands[best].element_size())
+            return (time.perf_counter() - t0) / n * 1e6
+        t_end = time.perf_counter() + warm_ms * 1e-3            # past the clock ramp behind the idle stretch of building the env
+        while time.perf_counter() < t_end:
+            timed(64)
+        cands, pads, times = [first], [], []
+        for k in range(trials):
+            if k:
+                # neighbouring allocations tend to share a speed class (runs of 3 - 9 alike among 16 consecutive candidates, whole
+                # sub-GiB regions alike in some processes): small paddings of varying size first, then, while no faster class has
+                # shown up, jumps of GiBs (the paddings are released with the losing candidates)
+                pad = ((k * 7) % 11 + 1) * (2 << 20) + (k % 3) * 4096
+                if k >= 6 and k % 3 == 0:
+                    jump = (1 << 30) * (1 + 2 * ((k - 6) // 3))
+                    if torch.cuda.mem_get_info(self.device)[0] > 4 * jump + nbytes:
+                        pad = jump
+                pads.append(torch.empty(pad, dtype=torch.uint8, device=self.device))
+                cands.append(torch.empty_like(first))
+            h.bind_buffer(which, cands[k].data_ptr(), nbytes)
+            timed(32)
+            times.append(timed(steps))
+            if k >= 3 and min(times) < 0.93 * max(times):
+                break
+        best = min(range(len(times)), key=times.__getitem__)
+        chosen = cands[best]
+        h.bind_buffer(which, chosen.data_ptr(), nbytes)
+        self._t[key] = chosen[:base.numel()].view(base.shape) if chosen.shape != base.shape else chosen
         h.step()                                                # the reset's step once more, into the block that stays
         self._view_cache = None
-        self.placement = {'us_per_step': [round(t, 2) for t in times], 'chosen': best}
+        self.placement = {'buffer': key, 'us_per_step': [round(t, 2) for t in times], 'chosen': best}
 
     def step(self, actions):
         """actions: int [B, num_agents] (torch CUDA tensor, or NumPy).  Returns (obs, rewards[B,N], dones[B], info).

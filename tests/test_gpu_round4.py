@@ -415,8 +415,8 @@ def test_obs_block_placement_trials(native):
     tuned = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic', placement_trials=3)
     auto = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic')
     o0, o1 = plain.reset(seed=4), tuned.reset(seed=4)
-    assert plain.placement is None and auto._placement_trials == 6            # 15 MB obs block, fused step: inside 'auto'
-    assert len(tuned.placement['us_per_step']) == 3 and 0 <= tuned.placement['chosen'] < 3
+    assert plain.placement is None and auto._placement_trials == 15           # 15 MB obs block, fused step: inside 'auto'
+    assert len(tuned.placement['us_per_step']) == 3 and 0 <= tuned.placement['chosen'] < 3 and tuned.placement['buffer'] == 'obs'
     assert torch.equal(o0, o1) and o1.data_ptr() == tuned._t['obs'].data_ptr()
     for k in range(3):
         act = torch.randint(0, 25 * 21, (256, 25), device=plain.device, dtype=torch.int32)
@@ -426,5 +426,14 @@ def test_obs_block_placement_trials(native):
     assert torch.equal(o0, o1) and len(tuned.placement['us_per_step']) == 3
     big = VecD2DEnv({'num_rbs': 64, 'num_cues': 100, 'num_due_pairs': 100}, num_envs=4)
     assert big._placement_trials == 0                                          # two launches per step: not the fused small-N case
-    for e in (plain, tuned, auto, big):
+    # the compact-obs step: the table is the block that is placed
+    from gym_d2d_amd.envs.obs_fn import OwnLinkObsFunction
+    t0 = VecD2DEnv({'num_rbs': 64, 'num_cues': 128, 'num_due_pairs': 128, 'obs_fn': OwnLinkObsFunction}, num_envs=512, placement_trials=0)
+    t1 = VecD2DEnv({'num_rbs': 64, 'num_cues': 128, 'num_due_pairs': 128, 'obs_fn': OwnLinkObsFunction}, num_envs=512, placement_trials=4)
+    a, b = t0.reset(seed=2), t1.reset(seed=2)
+    assert t1.placement['buffer'] == 'table' and 1 <= len(t1.placement['us_per_step']) <= 4 and torch.equal(a, b)
+    act = torch.randint(0, 64 * 21, (512, 256), device=t0.device, dtype=torch.int32)
+    ra, rb_ = t0.step(act), t1.step(act)
+    assert torch.equal(ra[0], rb_[0]) and torch.equal(ra[1], rb_[1]) and rb_[0].data_ptr() == t1._t['table'].data_ptr()
+    for e in (plain, tuned, auto, big, t0, t1):
         e.close()
