@@ -320,28 +320,39 @@ void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float*
     o.vec = (6 * N) % 4 == 0 ? 4 : 2;
     o.q_per_row = (unsigned)(6 * N / o.vec);
     o.q_magic = ((1ull << 40) + o.q_per_row - 1) / o.q_per_row;
-    // Launch geometry (tools/tune_obs.py, MI355X, N = 512): the fastest shape is the one where every thread
-    // issues exactly TWO 16-B stores - block = one row's float4 count (768), 2 rows per workgroup: 6.96 TB/s vs
-    // 5.9 TB/s for 96-KiB slabs and 5.6 TB/s for 786-KiB slabs.  Small slabs dispatched in order keep the
-    // chip-wide write front nearly sequential in address, and a workgroup never outlives its neighbours.
+    // Launch geometry.  Round 4 (tools/probes/obs_policy_geometry.py, MI355X, N = 512): FLAT slabs - the env's [N][6N] block as one
+    // flat array of float4, a 1024-thread workgroup writing two consecutive 16 KB pieces of it whatever the row length - the
+    // shape of the fastest fill of the probe family: 7.21 TB/s against 7.01 for the row-aligned shape of rounds 1-3 (768 threads
+    // = one row's float4 count, two 12 KB rows per workgroup) in interleaved rounds on one box; 3 or 4 pieces, 768- or 512-thread
+    // slabs and every scope-bit store policy are slower.  Rounds 1-3 (tools/tune_obs.py): among row-aligned shapes the fastest
+    // is the one where every thread issues exactly TWO 16-B stores (6.96 TB/s vs 5.9 for 96-KiB slabs and 5.6 for 786-KiB slabs):
+    // small slabs dispatched in order keep the chip-wide write front nearly sequential in address, and a workgroup never
+    // outlives its neighbours.  D2D_TUNE_OBS_VARIANT = 3 keeps the row-aligned kernel (A/B, and 8-byte rows when 6N % 4 != 0).
+    const bool flat = o.vec == 4 && (h->tune_variant == 0 || h->tune_variant == 2) && !h->obs_f64;
     int block = h->tune_block;
     if (block <= 0) {
-        block = (int)((o.q_per_row + 63) / 64) * 64;
+        block = flat ? 1024 : (int)((o.q_per_row + 63) / 64) * 64;
         if (block < 256) block = 256;
         if (block > 1024) block = 1024;
     }
     int rows = h->tune_rows;
     if (rows <= 0) {
-        rows = (int)((2u * (unsigned)block + o.q_per_row / 2) / o.q_per_row);
+        rows = flat ? 2 : (int)((2u * (unsigned)block + o.q_per_row / 2) / o.q_per_row);
         if (rows < 1) rows = 1;
     }
-    if (rows > N) rows = N;
+    if (rows > N && !flat) rows = N;
     o.rows_per_wg = rows;
     o.chunks = (N + rows - 1) / rows;
+    if (flat) {                                          // `rows` = consecutive pieces of `block` float4 per workgroup (at most 4)
+        if (rows > 4) rows = 4;
+        o.rows_per_wg = rows;
+        const unsigned total = (unsigned)N * o.q_per_row, slab = (unsigned)rows * (unsigned)block;
+        o.chunks = (int)((total + slab - 1) / slab);
+    }
     o.xcd_remap = (h->tune_xcd > 0 && B % (8 * h->tune_xcd) == 0) ? h->tune_xcd : 0;   // envs interleaved per XCD
     o.nontemporal = h->tune_nt;
     o.block = block;
-    o.variant = h->tune_variant;
+    o.variant = flat ? 2 : h->tune_variant;
     o.stagger = h->tune_stagger;
     o.out_f64 = 0;
     o.table = table;

@@ -6,9 +6,10 @@
 // This is the HBM-dominant kernel of the path: 24*N bytes written per agent-step against 24 read.  It is a
 // pure streaming store, so the design is about the store side only:
 //   * T[b] (6N floats) is staged once per workgroup in LDS;
-//   * the output block of an env is contiguous ([N][6N] floats), so a workgroup walks a contiguous slab of
-//     rows with one 16-byte store per lane per iteration - every wave-instruction writes 1 KiB of consecutive
-//     addresses (full 128-B lines, no partial-line read-modify-write);
+//   * the output block of an env is contiguous ([N][6N] floats), so a workgroup walks a contiguous slab of it
+//     with one 16-byte store per lane per iteration - every wave-instruction writes 1 KiB of consecutive
+//     addresses (full 128-B lines, no partial-line read-modify-write); since round 4 the slab is FLAT (two
+//     consecutive pieces of 1024 float4, whatever the row length: obs_expand_flat_kernel), before that two whole rows;
 //   * row i is T shifted by 6 floats for columns [6, 6(i+1)) and unshifted after that; both boundaries are
 //     even, so every aligned float2 of the output maps to one aligned float2 of T: two conflict-free
 //     ds_read_b64 feed each global_store_dwordx4;
@@ -126,6 +127,52 @@ __global__ __launch_bounds__(1024) void obs_expand_kernel(const ObsArgs a) {
     }
 }
 
+// Flat slabs - the default for 16-byte rows since round 4: the env's [N][6N] block is one flat array of N * 6N / 4 float4 and a workgroup
+// of T threads writes `flat_passes` x T consecutive float4 of it, whatever the row length - the shape of the fastest fill of the
+// probe family (1024 threads x 2 passes = 32 KB per workgroup, 16 KB contiguous per pass), where the row-aligned default writes
+// 2 x 12 KB.  A lane's (row, column) differs per pass: two multiply-shift divisions per lane and launch.
+template <int NT>
+__global__ __launch_bounds__(1024) void obs_expand_flat_kernel(const ObsArgs a) {
+    extern __shared__ __align__(16) float t_flat[];          // [6N]
+    const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
+    unsigned env, chunk;
+    if (a.xcd_remap) {
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
+        chunk = rest % a.chunks; env = (rest / a.chunks) * 8u + lane8;
+    } else {
+        env = blockIdx.x / a.chunks; chunk = blockIdx.x % a.chunks;
+    }
+    const unsigned row_floats = 6u * N, q_per_row = a.q_per_row, total = N * q_per_row;
+    {
+        const f32x2* src = reinterpret_cast<const f32x2*>(a.table + (size_t)env * row_floats);
+        f32x2* dst = reinterpret_cast<f32x2*>(t_flat);
+        for (unsigned k = tid; k < row_floats / 2; k += T) dst[k] = src[k];
+    }
+    __syncthreads();
+    if (a.stagger > 0) {                                                  // D2D_TUNE_OBS_STAGGER (A/B)
+        const int n = (int)(tid >> 6) * a.stagger;
+        for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);
+    }
+    const f32x2* t2 = reinterpret_cast<const f32x2*>(t_flat);
+    f32x4* out = reinterpret_cast<f32x4*>(a.obs + (size_t)env * N * row_floats);
+    const unsigned base = chunk * (unsigned)a.rows_per_wg * T;            // rows_per_wg = passes per workgroup here
+    f32x4 v[4];
+    unsigned idx[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        idx[p] = base + (unsigned)p * T + tid;
+        if (p < a.rows_per_wg && idx[p] < total) {
+            const unsigned i = (unsigned)(((unsigned long long)idx[p] * a.q_magic) >> 40), q = idx[p] - i * q_per_row;
+            const unsigned f = q * 4u;
+            const f32x2 lo = t2[src_col(f, i) >> 1], hi = t2[src_col(f + 2u, i) >> 1];
+            v[p] = f32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (p < a.rows_per_wg && idx[p] < total) store16<NT>(out + idx[p], v[p]);
+}
+
 // The same expansion written as float64 (d2d_set_obs_dtype: the reference's observation dtype, obs_fn.py:47,51 builds float64
 // arrays): every aligned float2 of T becomes one 16-byte double2 store, so the widening happens on the way out and the [B,N,6N]
 // block is written once - 48 N bytes per agent-step instead of 24 N written, 24 N re-read and 48 N written by a separate cast.
@@ -213,6 +260,17 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     }
     if (a.variant == 1 && a.vec == 4) {
         hipLaunchKernelGGL(obs_expand_direct_kernel, grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (a.variant == 2 && a.vec == 4 && a.rows_per_wg <= 4) {
+        switch (a.nontemporal) {
+            case 0: hipLaunchKernelGGL((obs_expand_flat_kernel<0>), grid, block, lds, stream, a); break;
+            case 2: hipLaunchKernelGGL((obs_expand_flat_kernel<2>), grid, block, lds, stream, a); break;
+            case 3: hipLaunchKernelGGL((obs_expand_flat_kernel<3>), grid, block, lds, stream, a); break;
+            case 4: hipLaunchKernelGGL((obs_expand_flat_kernel<4>), grid, block, lds, stream, a); break;
+            case 5: hipLaunchKernelGGL((obs_expand_flat_kernel<5>), grid, block, lds, stream, a); break;
+            default: hipLaunchKernelGGL((obs_expand_flat_kernel<1>), grid, block, lds, stream, a); break;
+        }
         return hipGetLastError();
     }
     if (a.vec == 4) {

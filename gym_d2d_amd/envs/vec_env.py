@@ -301,8 +301,11 @@ class VecD2DEnv:
                     jump = (1 << 30) * (1 + 2 * ((k - 6) // 3))
                     if torch.cuda.mem_get_info(self.device)[0] > 4 * jump + nbytes:
                         pad = jump
-                pads.append(torch.empty(pad, dtype=torch.uint8, device=self.device))
-                cands.append(torch.empty_like(first))
+                try:
+                    pads.append(torch.empty(pad, dtype=torch.uint8, device=self.device))
+                    cands.append(torch.empty_like(first))
+                except torch.cuda.OutOfMemoryError:             # a crowded GPU: choose among what there is
+                    break
             h.bind_buffer(which, cands[k].data_ptr(), nbytes)
             timed(32)
             times.append(timed(steps))
@@ -315,6 +318,11 @@ class VecD2DEnv:
         h.step()                                                # the reset's step once more, into the block that stays
         self._view_cache = None
         self.placement = {'buffer': key, 'us_per_step': [round(t, 2) for t in times], 'chosen': best}
+        if len(cands) > 1:
+            # the losing candidates and the paddings (up to a few GiB) go back to the driver, not into torch's cache
+            del cands, pads, first
+            torch.cuda.synchronize(self.device)
+            torch.cuda.empty_cache()
 
     def step(self, actions):
         """actions: int [B, num_agents] (torch CUDA tensor, or NumPy).  Returns (obs, rewards[B,N], dones[B], info).

@@ -199,7 +199,8 @@ typedef enum d2d_tuning {
                                       4 sc0 sc1 nt, 5 sc1 nt (the scope bits of the gfx942+ store encoding)            */
     D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
     D2D_TUNE_OBS_BLOCK = 3,        /* threads per obs workgroup; 0 = auto                            */
-    D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): T staged in LDS; 1: T read from global (A/B)      */
+    D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): flat 32 KB slabs, T staged in LDS; 1: T read from global (A/B);
+                                      3: the row-aligned kernel of rounds 1-3 (A/B)                    */
     D2D_TUNE_OBS_STAGGER = 16,     /* A/B: wave w of an obs workgroup sleeps w * value * 64 clocks before its stores; 0 (default) off */
     D2D_TUNE_STEP_THREADS = 5,     /* threads per ENV in the step kernel; 0 = auto (one per link).  Below half the link
                                       count no link sits in registers (strided kernel) and the per-RB search

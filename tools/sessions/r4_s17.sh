@@ -1,0 +1,6 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4_s17; mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/tests.log
+timeout 900 python tools/probes/obs_policy_geometry.py > $O/obs_policy_geometry.jsonl 2> $O/obs_policy_geometry.err
+echo done
