@@ -480,7 +480,7 @@ class Session:
             # dominant kernel: obs expansion.  Algorithmic bytes per launch = B*N*(24N written + 24 read of T)
             per_launch = b * n * (24.0 * n + 24.0)
             avg_ms = t['obs_ms'] / t['obs_n']
-            roof = {'kernel': 'obs_expand_kernel'}
+            roof = {'kernel': 'obs_expand_flat_kernel'}
         else:
             per_launch = b * n * algorithmic_bytes(n, self.obs, getattr(self, 'reward_per_env', False))
             avg_ms = t['step_ms'] / max(t['step_n'], 1)
@@ -704,7 +704,7 @@ def worker(args):
         roof = sess.roofline(t)
         if extras.get('box_write_ceiling'):
             roof['box_ceiling_GBs'] = extras['box_write_ceiling']['GBps']
-            roof['frac_of_box_ceiling'] = roof['achieved'] / roof['box_ceiling_GBs'] if roof['kernel'] == 'obs_expand_kernel' else None
+            roof['frac_of_box_ceiling'] = roof['achieved'] / roof['box_ceiling_GBs'] if roof['kernel'].startswith('obs_expand') else None
             roof['box_ceiling_note'] = ('the best store-only kernel this library could build on this box (box_write_ceiling: plain fills in 32 geometries, '
                                         'hipMemsetAsync, and fills with the obs kernel\'s load + barrier structure and scope-bit stores)')
         cfg = sess.config(world, (f' + per-step all-gather ({args.gather}: rewards' + (', (sinr, snr) columns of the obs table'
@@ -908,7 +908,9 @@ def attach_traffic(roof, workload, obs, custom_envs, export=True):
         if obs != 'linear' and ('--no-export' in rec.get('command', '')) == bool(export):
             continue            # collected with / without the decoded (rb, pwr) planes: 8 bytes per link apart
         for kname, d in rec.get('kernels', {}).items():
-            if roof['kernel'].split(' ')[0] in kname and 'hbm_bytes_per_launch' in d:
+            tag = roof['kernel'].split(' ')[0]
+            tag = 'obs_expand' if tag.startswith('obs_expand') else tag      # obs_expand_flat_kernel / obs_expand_kernel / obs_expand_f64_kernel
+            if tag in kname and 'hbm_bytes_per_launch' in d:
                 if rec.get('source_digest') == digest:
                     roof['traffic'] = d['hbm_bytes_per_launch']
                     roof['traffic_source'] = (f'QUOTED, not measured in this run: profiles/{path.name} (WRITE_SIZE + 2*FETCH_SIZE, '
