@@ -383,7 +383,8 @@ class Session:
             tune_keys = {'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
                          'xcd': _native.TUNE_OBS_XCD_REMAP, 'block': _native.TUNE_OBS_BLOCK,
                          'threads': _native.TUNE_STEP_THREADS, 'epw': _native.TUNE_STEP_ENVS_PER_WG,
-                         'sblock': _native.TUNE_STEP_BLOCK, 'fuse': _native.TUNE_STEP_FUSE_OBS, 'walk': _native.TUNE_STEP_WALK}
+                         'sblock': _native.TUNE_STEP_BLOCK, 'fuse': _native.TUNE_STEP_FUSE_OBS, 'walk': _native.TUNE_STEP_WALK,
+                         'prefetch': _native.TUNE_STEP_PREFETCH, 'lpt': _native.TUNE_STEP_LPT, 'variant': _native.TUNE_OBS_VARIANT}
             for kv in filter(None, tune.split(',')):
                 k, v = kv.split('=')
                 if k == 'bucket':
