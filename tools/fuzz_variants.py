@@ -43,7 +43,7 @@ def main():
         rbs = int(rng.choice([1, 2, 5, 16, 64, 300, max(1, (cues + dues) // 2)]))
         b = int(rng.integers(1, 20)) if cues + dues > 600 else int(rng.integers(1, 70))
         reward = int(rng.integers(1, 4))
-        linear = cues + dues <= 128 and rng.random() < 0.5
+        linear = (cues + dues <= 128 and rng.random() < 0.5) or (cues + dues <= 400 and rng.random() < 0.25)   # beyond 128 links: the stand-alone expansion
         model = rng.choice(['log2', 'ple'])
         cfg = dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b)
         if model == 'ple':
@@ -87,7 +87,11 @@ def main():
                     nat.TUNE_STEP_NT_RESULTS: int(rng.choice([0, 1])), nat.TUNE_STEP_OBS_ROTATE: int(rng.choice([-1, 0, 7])),
                     nat.TUNE_STEP_LPT: int(rng.choice([-1, 1, 2])) if cues + dues <= 1024 else -1,
                     nat.TUNE_STEP_ENVS_PER_WG: int(rng.choice([0, 1, 2, 4])) if cues + dues <= 128 else 0,
-                    nat.TUNE_STEP_FUSE_OBS: int(rng.choice([-1, 0, 1])) if linear else -1}
+                    nat.TUNE_STEP_FUSE_OBS: int(rng.choice([-1, 0, 1])) if linear and cues + dues <= 128 else -1,
+                    # round 4: the stand-alone expansion's shapes (flat slabs / row-aligned / no LDS), slab sizes, store policies
+                    nat.TUNE_OBS_VARIANT: int(rng.choice([0, 3, 1])), nat.TUNE_OBS_BLOCK: int(rng.choice([0, 256, 512, 768, 1024])),
+                    nat.TUNE_OBS_ROWS_PER_WG: int(rng.choice([0, 1, 2, 3, 4, 7])), nat.TUNE_OBS_NONTEMPORAL: int(rng.choice([1, 1, 0, 2, 3, 4, 5])),
+                    nat.TUNE_STEP_BLOCK: int(rng.choice([0, 0, 256, 512, 1024])) if linear and cues + dues <= 64 else 0}
             if tune[nat.TUNE_STEP_LPT] == 1 and cues + dues > 1024:
                 tune[nat.TUNE_STEP_LPT] = -1
             for k, v in tune.items():
@@ -96,9 +100,27 @@ def main():
             h.set_export_actions(export)
             if not export:
                 h.upload(nat.BUF_RB, ref['BUF_RB']); h.upload(nat.BUF_PWR, ref['BUF_PWR'])
+            # round 4: the per-env reward layout, the obs-less mode, float64 obs - each leaves every other output as it was
+            per_env = reward == 1 and rng.random() < 0.4
+            obs_none = (not linear) and rng.random() < 0.3
+            obs64 = linear and rng.random() < 0.25
+            h.set_reward_layout(nat.REWARD_PER_ENV if per_env else nat.REWARD_PER_AGENT)
+            h.set_obs_mode(nat.OBS_NONE if obs_none else (nat.OBS_LINEAR if linear else nat.OBS_TABLE))
+            h.set_obs_dtype(nat.F64 if obs64 else nat.F32)
+            if per_env:
+                h.upload(nat.BUF_REWARD, ref['BUF_REWARD'])
+            if obs_none:
+                h.upload(nat.BUF_OBS_TABLE, ref['BUF_OBS_TABLE'])
             sim.step_arrays(raw)
             got = snap(sim, linear)
             runs += 1
+            if per_env and not np.array_equal(sim.fetch(nat.BUF_REWARD_ENV), ref['BUF_REWARD'][:, 0], equal_nan=True) and tune[nat.TUNE_STEP_LPT] != 2:
+                print('MISMATCH per-env reward', dict(b=b, rbs=rbs, cues=cues, dues=dues), {int(k): v for k, v in tune.items()}, flush=True)
+                sys.exit(1)
+            if obs64:
+                got['BUF_OBS'] = got['BUF_OBS'].astype(np.float32) if np.array_equal(got['BUF_OBS'], got['BUF_OBS'].astype(np.float32).astype(np.float64), equal_nan=True) else got['BUF_OBS'] * np.nan
+            h.set_reward_layout(nat.REWARD_PER_AGENT); h.set_obs_dtype(nat.F32)
+            h.set_obs_mode(nat.OBS_LINEAR if linear else nat.OBS_TABLE)
             for name, r in ref.items():
                 if name == 'BUF_REWARD' and reward == 1 and tune[nat.TUNE_STEP_LPT] == 2 and cues + dues <= 1024:
                     # two links per thread add the capacities in another order than one link per thread: last-bit differences
