@@ -751,6 +751,18 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             for (int k = 0; k < 32; ++k) { x0 = fmaf(x0, 1.0001f, 0.5f); x1 = fmaf(x1, 0.9999f, 0.25f); }
             if (x0 + x1 == 1.2345f) my_flags |= 1 << 29;
         }
+        if (ABL(524288)) {                   // diagnostic: 64 extra full-rate VALU instructions per wave that cannot be packed (the FMA
+                                             // chains above compile to 32 dependent v_pk_fma_f32): four independent integer chains
+            unsigned y0 = (unsigned)i, y1 = (unsigned)rb, y2 = y0 + 7u, y3 = y1 + 9u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(y0) : "v"(y1));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(y1) : "v"(y2));
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(y2) : "v"(y3));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(y3) : "v"(y0));
+            }
+            if ((y0 ^ y1 ^ y2 ^ y3) == 0x12345679u) my_flags |= 1 << 26;
+        }
         if (ABL(32768)) {                    // diagnostic: 64 extra SALU instructions per wave (wave-uniform integer chain)
             int sx = __builtin_amdgcn_readfirstlane(rb);
 #pragma unroll
