@@ -625,6 +625,8 @@ def worker(args):
                             reward_every=args.reward_every if mode == 'rewards' else 1,
                             backend='native' if native else 'torch', handle=sess.h if native else None)
 
+    if args.obs == 'none' and args.gather == 'table':
+        args.gather = 'planes'                 # no table exists in the obs-less mode: the (sinr, snr) planes travel instead (same bytes)
     gatherer = make_gatherer(args.gather, args.signal_every) if use_dist and not args.no_gather else None
     total_steps = args.steps + args.warmup                    # launches the gatherer sees in the timed run (warm-up included)
     t = sess.timed(fence, gatherer, args.with_reset)
@@ -708,9 +710,10 @@ def worker(args):
             roof['frac_of_box_ceiling'] = roof['achieved'] / roof['box_ceiling_GBs'] if roof['kernel'].startswith('obs_expand') else None
             roof['box_ceiling_note'] = ('the best store-only kernel this library could build on this box (box_write_ceiling: plain fills in 32 geometries, '
                                         'hipMemsetAsync, and fills with the obs kernel\'s load + barrier structure and scope-bit stores)')
-        cfg = sess.config(world, (f' + per-step all-gather ({args.gather}: rewards' + (', (sinr, snr) columns of the obs table'
-                                  + (f' every {args.signal_every} steps' if args.signal_every > 1 else '') if args.gather == 'table' else '')
-                                  + '; position columns once per episode)') if gatherer else '')
+        carried = {'table': ', (sinr, snr) columns of the obs table', 'planes': ', the (sinr, snr) result planes', 'rewards': ''}[args.gather]
+        if carried and args.signal_every > 1:
+            carried += f' every {args.signal_every} steps'
+        cfg = sess.config(world, f' + per-step all-gather ({args.gather}: rewards{carried}; position columns once per episode)' if gatherer else '')
         cfg['positions'] = 'redrawn on the device every 10 steps' if args.with_reset else 'fixed over the run'
         out = {
             'metric': 'env agent-steps/sec (batch x agents)', 'value': value, 'unit': 'agent-steps/s',

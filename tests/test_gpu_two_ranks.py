@@ -150,6 +150,24 @@ def test_bench_two_ranks_on_one_gpu_agree_with_one_rank_of_twice_the_envs():
     assert abs(two['allgather_reward_checksum'] - 2 * rank0['allgather_reward_checksum']) > 1e-3
 
 
+def test_bench_two_ranks_obs_less_learner_configuration():
+    """`bench.py --gpus 2 --share-gpu --obs none --reward-per-env --no-export`: every rank runs D2D_OBS_NONE through the public API and the
+    per-step gather is the planes plan (chosen by itself: no table exists); the collectives saw both ranks and the gathered per-env
+    rewards sum to the all-reduced local sums."""
+    import json
+    import subprocess
+    cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--share-gpu', '--workload', 'default', '--obs', 'none', '--reward-per-env',
+           '--no-export', '--envs', '64', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-single-env-latency']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert two['n_gpus'] == 2 and two['allgather_envs'] == 128 and two['checksums_agree'] is True
+    g = two['gather']
+    assert g['mode'] == 'planes' and g['bytes_per_gpu_per_step'] == 64 * 4 + 64 * 50 * 2 * 4
+    assert two['config']['obs_mode'] == 'none' and two['algorithmic_bytes_per_agent_step'] == 36.0 + 4.0 / 50
+
+
 def test_bench_native_gather_backend_with_one_rank():
     """`bench.py --gather-backend native`: the per-step gather through the C ABI's own RCCL entry (d2d_comm_init /
     d2d_allgather on the side stream) instead of torch.distributed - with one rank, which is all RCCL admits on a one-GPU box;
