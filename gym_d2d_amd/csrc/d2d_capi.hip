@@ -396,7 +396,11 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // than four links per RB on average a ninth link on some RB is the rule, the list build is wasted and the workgroup
     // sweeps all pairs anyway (N > 8 R: by pigeonhole), so those shapes go straight to the sweep
     const bool lists_can_help = (long long)N <= 4ll * h->cfg.num_rbs;
-    s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (N > 1024 && lists_can_help ? 2 : 0);
+    // ... and in the obs-less mode (D2D_OBS_NONE), where the step is paced by its instruction streams rather than its stores: the
+    // lists' fixed batches of clamped pair evaluations (no exec-mask loops) take the rollout kernel from 21.0 to 19.5 us at 4096 x 512,
+    // while in the table modes, which are memory bound, they cost 1 - 4 % (profiles/r4_hot_member_lists_ab.jsonl)
+    const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE);
+    s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (lists_pay ? 2 : 0);
 
     // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
     // workgroup (N = 50: four 64-thread envs in 256 threads), and for small N the LinearObs expansion runs inside the

@@ -28,7 +28,8 @@
 //     word requested before the current one's members are consumed.  Beyond 1024 links per env (the summary word's reach)
 //     per-RB member lists take over (slot counter + eight u16 slots per RB, sorted in registers by the receiver).  A masked
 //     all-pairs sweep is the fallback (rb outside [0,R), nothing fits in LDS, a list overflows where no masks exist).  All
-//     of them visit interferers in ascending link index through the same fmaf, hence produce identical bits.  Measured
+//     of them visit interferers in ascending link index through the same fmaf, hence produce identical bits.  (Round 4: the
+//     lists are also what the rollout kernel uses in the obs-less mode, where instructions, not stores, pace the step.)  Measured
 //     and rejected, with the evidence under profiles/: a stable counting sort by RB (r2: 40.0 vs 35.3 us), a flattened
 //     walk, the member lists in the rollout kernel (r3: 31.7 vs 30.8 us - the walk is not what paces the kernel);
 //   * what paces the kernel is the memory pipeline: bytes and vector-memory requests (dropping the optional decoded
@@ -1140,9 +1141,9 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool full = lpt > 0 && a.epw == 1 && a.N == lpt * a.tpe && block_threads == a.tpe && !a.fuse_obs;
     const bool lists = a.walk == 2 && lpt > 0 && a.reward_fn != 3;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 &&
-                     a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
+                     (a.walk == 0 || lists) && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
-    const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0);
+    const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0) | (lists ? OPT_LISTS : 0);
     // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
@@ -1165,6 +1166,10 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
             case 0: D2D_LAUNCH_1(M, 1, true, 1, 0); break;                                               \
             case OPT_SREC: D2D_LAUNCH_1(M, 1, true, 1, OPT_SREC); break;                                 \
             case OPT_NT: D2D_LAUNCH_1(M, 1, true, 1, OPT_NT); break;                                     \
+            case OPT_LISTS: D2D_LAUNCH_1(M, 1, true, 1, OPT_LISTS); break;                               \
+            case OPT_LISTS | OPT_SREC: D2D_LAUNCH_1(M, 1, true, 1, OPT_LISTS | OPT_SREC); break;         \
+            case OPT_LISTS | OPT_NT: D2D_LAUNCH_1(M, 1, true, 1, OPT_LISTS | OPT_NT); break;             \
+            case OPT_LISTS | OPT_SREC | OPT_NT: D2D_LAUNCH_1(M, 1, true, 1, OPT_LISTS | OPT_SREC | OPT_NT); break; \
             default: D2D_LAUNCH_1(M, 1, true, 1, OPT_SREC | OPT_NT); break;                              \
         }                                                                                                \
     } while (0)
