@@ -437,3 +437,46 @@ def test_obs_block_placement_trials(native):
     assert torch.equal(ra[0], rb_[0]) and torch.equal(ra[1], rb_[1]) and rb_[0].data_ptr() == t1._t['table'].data_ptr()
     for e in (plain, tuned, auto, big, t0, t1):
         e.close()
+
+
+def _golden_names():
+    from golden_util import case_names
+    return [n for n in case_names() if 'shadowing' not in n]
+
+
+@pytest.mark.parametrize('name', _golden_names())
+def test_golden_cases_in_the_round4_modes(native, name):
+    """Every captured reference case (tests/golden, made by running the reference) through the modes round 4 added: the obs-less step
+    with the per-env reward (where the library takes the member lists by itself) - SINR / SNR / rate / capacity and
+    SystemCapacity's scalar within 1e-5 of the reference, the link-position rows bit-exact - and the float64 obs block of
+    d2d_set_obs_dtype within 1e-5 of the reference's float64 observations."""
+    from golden_util import load_case
+    from sim_util import env_config_for
+    from gym_d2d_amd.simulator import Simulator
+    case = load_case(name)
+    sim = Simulator(env_config_for(case))
+    sim.set_positions(case.pos[None].astype(np.float32))
+    h = sim.handle
+    for k, s in enumerate(case.steps):
+        sim.set_links([tuple(key.split(':')) for key in s.keys])
+        tag = (name, k)
+        h.set_reward(native.REWARD_SYSTEM_CAPACITY, 0.0)
+        h.set_obs_mode(native.OBS_NONE)
+        h.set_reward_layout(native.REWARD_PER_ENV)
+        h.set_export_actions(False)
+        sim.step_arrays(rb=s.rb[None], pwr=s.pwr[None])
+        assert sim.check_flags() & native.FLAG_ZERO_DISTANCE == 0
+        for f, buf in (('sinr_db', native.BUF_SINR_DB), ('snr_db', native.BUF_SNR_DB), ('rate_bps', native.BUF_RATE_BPS),
+                       ('capacity_mbps', native.BUF_CAPACITY)):
+            assert rel_err(sim.fetch(buf)[0], getattr(s, f)) <= TOL, (tag, f)
+        assert rel_err(sim.fetch(native.BUF_REWARD_ENV), np.asarray(s.reward_system_capacity).reshape(-1)[:1]) <= TOL, tag
+        assert (h.download(native.BUF_LINK_POS)[0] == s.obs_table[:, :4].astype(np.float32)).all(), tag
+        h.set_obs_mode(native.OBS_LINEAR)
+        h.set_reward_layout(native.REWARD_PER_AGENT)
+        h.set_obs_dtype(native.F64)
+        sim.step_arrays(rb=s.rb[None], pwr=s.pwr[None])
+        obs = sim.fetch(native.BUF_OBS)[0]
+        assert obs.dtype == np.float64 and rel_err(obs[s.obs_rows], s.obs) <= TOL, tag
+        h.set_obs_dtype(native.F32)
+        h.set_export_actions(True)
+    h.close()
