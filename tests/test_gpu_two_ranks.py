@@ -150,6 +150,27 @@ def test_bench_two_ranks_on_one_gpu_agree_with_one_rank_of_twice_the_envs():
     assert abs(two['allgather_reward_checksum'] - 2 * rank0['allgather_reward_checksum']) > 1e-3
 
 
+def test_bench_two_ranks_headline_shape_with_core_mode_gathers():
+    """The driver's N > 1 command line in miniature: the stress workload's shape (512 links, LinearObs: two kernels per step) with
+    two ranks sharing the GPU, so that `core_mode` runs WITH its gatherers - the rewards ring for the table entries and the planes
+    plan for `planes_only` - which no one-rank run reaches."""
+    import json
+    import subprocess
+    cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--share-gpu', '--envs', '16', '--steps', '8', '--warmup', '2',
+           '--no-cpu-baseline', '--no-single-env-latency']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert two['n_gpus'] == 2 and two['checksums_agree'] is True and two['gather']['mode'] == 'table'
+    core = two['core_mode']
+    assert core['gather']['mode'] == 'rewards' and core['value'] > 0 and core['with_decoded_rb_pwr_export']['value'] > 0
+    po = core['planes_only']
+    assert po['gather']['mode'] == 'planes' and po['gather']['bytes_per_gpu_per_step'] == 16 * 4 + 16 * 512 * 8 and po['value'] > 0
+    assert abs(po['algorithmic_bytes_per_agent_step'] - (36.0 + 4.0 / 512)) < 1e-9
+    assert two['cpu_baseline'].startswith('N=1 line only')
+
+
 def test_bench_two_ranks_obs_less_learner_configuration():
     """`bench.py --gpus 2 --share-gpu --obs none --reward-per-env --no-export`: every rank runs D2D_OBS_NONE through the public API and the
     per-step gather is the planes plan (chosen by itself: no table exists); the collectives saw both ranks and the gathered per-env
