@@ -64,7 +64,7 @@ class VecD2DEnv:
         first reset() times a few hundred steps on up to K candidate blocks (allocated one by one behind paddings of varying
         size - megabytes at first, GiBs from the seventh on - all held until the choice) and keeps the fastest; it stops early once a candidate is 7 % faster than the slowest
         seen (a faster class has shown up).  About 5 ms per candidate at config 2, 8 ms at stress sizes, once per env.
-        'auto' = 15 for an obs block (fused LinearObs step) or a table (compact obs) of 8 ... 256 MB - larger blocks average the
+        'auto' = 24 for an obs block (fused LinearObs step) or a table (compact obs) of 8 ... 256 MB - larger blocks average the
         effect out (the 25.8 GB block of config 3 is one speed everywhere) - else 0.
 
         step()'s `dones` on the torch path is one of two preallocated CONSTANT tensors (all False / all True), shared by
@@ -152,7 +152,7 @@ class VecD2DEnv:
             if self.use_torch and self._placement_target is not None:
                 t = self._t[self._placement_target[0]]
                 nbytes = t.numel() * t.element_size()
-            placement_trials = 15 if (8 << 20) <= nbytes <= (256 << 20) else 0
+            placement_trials = 24 if (8 << 20) <= nbytes <= (256 << 20) else 0
         self._placement_trials = int(placement_trials) if self.use_torch and self._placement_target is not None else 0
         self.placement = None                      # after the trials: {'buffer': ..., 'us_per_step': [...], 'chosen': k}
 
@@ -298,7 +298,7 @@ class VecD2DEnv:
                 # shown up, jumps of GiBs (the paddings are released with the losing candidates)
                 pad = ((k * 7) % 11 + 1) * (2 << 20) + (k % 3) * 4096
                 if k >= 6 and k % 3 == 0:
-                    jump = (1 << 30) * (1 + 2 * ((k - 6) // 3))
+                    jump = (1 << 30) * (1 + 2 * (((k - 6) // 3) % 3))      # 1, 3, 5 GiB, again
                     if torch.cuda.mem_get_info(self.device)[0] > 4 * jump + nbytes:
                         pad = jump
                 try:

@@ -415,7 +415,7 @@ def test_obs_block_placement_trials(native):
     tuned = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic', placement_trials=3)
     auto = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic')
     o0, o1 = plain.reset(seed=4), tuned.reset(seed=4)
-    assert plain.placement is None and auto._placement_trials == 15           # 15 MB obs block, fused step: inside 'auto'
+    assert plain.placement is None and auto._placement_trials == 24           # 15 MB obs block, fused step: inside 'auto'
     assert len(tuned.placement['us_per_step']) == 3 and 0 <= tuned.placement['chosen'] < 3 and tuned.placement['buffer'] == 'obs'
     assert torch.equal(o0, o1) and o1.data_ptr() == tuned._t['obs'].data_ptr()
     for k in range(3):
