@@ -854,7 +854,6 @@ def n1_extras(torch, args, dev, local, fence):
     # BASELINE.json configs[3]: FreeSpacePathLoss + a custom ObsFunction through the plugin ABI, 4096 x 512
     s = Session(torch, args, 'plugin', 'table', dev, 0, local, 1000, 1000, action_pool=64)      # 58 ms: as above
     out['other_workloads']['plugin'] = summarise(s, s.timed(fence), 1000)
-    out['other_workloads']['plugin']['table_placement_trials'] = getattr(s.env, 'placement', None)
     out['vec_env_step_ms']['stress sizes, compact obs (OwnLinkObsFunction)'] = s.vec_env_step_ms()
     s.close()
     # the stress workload as EPISODES: positions redrawn on the device every 10 steps (d2d_env.py:16,45-52), 3 episodes

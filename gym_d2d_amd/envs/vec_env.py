@@ -64,8 +64,9 @@ class VecD2DEnv:
         first reset() times a few hundred steps on up to K candidate blocks (allocated one by one behind paddings of varying
         size - megabytes at first, GiBs from the seventh on - all held until the choice) and keeps the fastest; it stops early once a candidate is 7 % faster than the slowest
         seen (a faster class has shown up).  About 5 ms per candidate at config 2, 8 ms at stress sizes, once per env.
-        'auto' = 24 for an obs block (fused LinearObs step) or a table (compact obs) of 8 ... 256 MB - larger blocks average the
-        effect out (the 25.8 GB block of config 3 is one speed everywhere) - else 0.
+        'auto' = 24 for the obs block of the fused LinearObs step when it is 8 ... 256 MB - larger blocks average the effect out
+        (the 25.8 GB block of config 3 is one speed everywhere) - else 0; an explicit K also places the table of a compact-obs env
+        (its classes only show with fresh actions every step, which the trials do not generate: measured 25.0 us for all 24).
 
         step()'s `dones` on the torch path is one of two preallocated CONSTANT tensors (all False / all True), shared by
         every call: treat it as read-only (clone it before an in-place update).
@@ -152,7 +153,8 @@ class VecD2DEnv:
             if self.use_torch and self._placement_target is not None:
                 t = self._t[self._placement_target[0]]
                 nbytes = t.numel() * t.element_size()
-            placement_trials = 24 if (8 << 20) <= nbytes <= (256 << 20) else 0
+            # the table's classes only show under fresh actions per step (the trials step with the reset's own, repeated): opt-in there
+            placement_trials = 24 if (8 << 20) <= nbytes <= (256 << 20) and self._placement_target[0] == 'obs' else 0
         self._placement_trials = int(placement_trials) if self.use_torch and self._placement_target is not None else 0
         self.placement = None                      # after the trials: {'buffer': ..., 'us_per_step': [...], 'chosen': k}
 
