@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 GPU session 7 (kernel sources frozen): tests, driver-like bench line, rocprofv3 evidence for every configuration the
+# Round-4 evidence session (kernel sources frozen; ran as r4_s7, s18, s28 and, finally, s31): tests, driver-like bench line, rocprofv3 evidence for every configuration the
 # bench line quotes traffic for.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4_s18; mkdir -p $O/profiles
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4_evidence; mkdir -p $O/profiles
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/tests.log 2>&1; echo "tests rc=$?" | tee -a $O/tests.log
 for spec in "stress linear 100" "stress table 2000 --no-export" "stress table 2000" "plugin table 2000" "default linear 4000" \
