@@ -480,3 +480,25 @@ def test_golden_cases_in_the_round4_modes(native, name):
         h.set_obs_dtype(native.F32)
         h.set_export_actions(True)
     h.close()
+
+
+def test_numpy_path_of_the_round4_options(native):
+    """VecD2DEnv(use_torch=False) - host arrays in and out, the library owning every buffer - with the per-env reward, the obs-less
+    observation and export off: the same numbers as the torch path."""
+    import torch
+    from gym_d2d_amd.envs import VecD2DEnv
+    from gym_d2d_amd.envs.obs_fn import SignalPlanesObsFunction
+    cfg = {'num_rbs': 8, 'num_cues': 12, 'num_due_pairs': 20, 'obs_fn': SignalPlanesObsFunction}
+    t = VecD2DEnv(dict(cfg), num_envs=24, export_actions=False, reward_per_env=True)
+    n = VecD2DEnv(dict(cfg), num_envs=24, export_actions=False, reward_per_env=True, use_torch=False)
+    (ts, tn), (ns, nn) = t.reset(seed=8), n.reset(seed=8)
+    assert isinstance(ns, np.ndarray) and np.array_equal(ts.cpu().numpy(), ns) and np.array_equal(tn.cpu().numpy(), nn)
+    assert np.array_equal(t.link_positions().cpu().numpy(), n.link_positions())
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        act = rng.integers(0, 8 * 21, (24, 32)).astype(np.int32)
+        (ts, tn), tr, td, ti = t.step(torch.as_tensor(act, device=t.device))
+        (ns, nn), nr, nd, ni = n.step(act)
+        assert nr.shape == (24,) and np.array_equal(tr.cpu().numpy(), nr) and np.array_equal(ts.cpu().numpy(), ns)
+        assert ni['rb'] is None and ni['tx_pwr_dbm'] is None and np.array_equal(ti['capacity_mbps'].cpu().numpy(), ni['capacity_mbps'])
+    t.close(); n.close()
