@@ -1277,21 +1277,22 @@ int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double*
     if (bytes < group) return fail(D2D_ERR_INVALID, "the probe needs at least 64 MiB");
     USE_DEVICE(h);
     float* tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, bytes));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipMalloc(&tmp, bytes);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
     const int variants = d2d::fill_variants();
     double best = 0.0;
-    int rc = D2D_OK;
+    int rc = err == hipSuccess ? D2D_OK : fail(D2D_ERR_HIP, std::string("d2d_probe_write_variants: ") + hipGetErrorString(err));
     for (int v = 0; v <= variants && rc == D2D_OK; ++v) {      // v == variants: the runtime's own fill (hipMemsetAsync)
         double rate = 0.0;
         rc = time_fill(h, tmp, bytes, nullptr, v < variants ? v : -1, 0, iters, e0, e1, &rate);
         if (v < n) per_variant[v] = rate;
         if (rate > best) best = rate;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(tmp);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (tmp) (void)hipFree(tmp);
     if (rc) return rc;
     *best_gb_per_s = best;
     return D2D_OK;
@@ -1304,20 +1305,21 @@ int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t v
     const size_t group = (size_t)8 * 512 * 1024 * 16;
     if (bytes < group) return fail(D2D_ERR_INVALID, "the probe needs at least 64 MiB");
     USE_DEVICE(h);
-    float* tmp = static_cast<float*>(dst_dev);
-    if (!dst_dev) HIP_TRY(hipMalloc(&tmp, bytes));
     // the staged forms read one 1024-float4 row per region of 512 rows: a table 1 / 512 of the destination, as in the obs kernel
-    float* src = nullptr;
+    float *tmp = static_cast<float*>(dst_dev), *src = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     const size_t src_bytes = bytes / 512 + (size_t)1024 * 16;
-    HIP_TRY(hipMalloc(&src, src_bytes));
-    HIP_TRY(hipMemsetAsync(src, 0, src_bytes, h->stream));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    const int rc = time_fill(h, tmp, bytes, src, variant, stagger, iters, e0, e1, gb_per_s);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(src);
-    if (!dst_dev) (void)hipFree(tmp);
+    hipError_t err = hipMalloc(&src, src_bytes);
+    if (err == hipSuccess && !dst_dev) err = hipMalloc(&tmp, bytes);
+    if (err == hipSuccess) err = hipMemsetAsync(src, 0, src_bytes, h->stream);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    int rc = err == hipSuccess ? time_fill(h, tmp, bytes, src, variant, stagger, iters, e0, e1, gb_per_s)
+                               : fail(D2D_ERR_HIP, std::string("d2d_probe_write_staged: ") + hipGetErrorString(err));
+    if (e0) (void)hipEventDestroy(e0);                  // every exit releases what was allocated
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (!dst_dev && tmp) (void)hipFree(tmp);
     return rc;
 }
 
