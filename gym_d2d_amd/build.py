@@ -18,8 +18,8 @@ LIB_PATH = LIB_DIR / 'libd2d_hip.so'
 INCLUDE = PKG.parent / 'include'
 ARCH = 'gfx950'
 
-SOURCES = ['d2d_step.hip', 'd2d_obs.hip', 'd2d_reset.hip', 'd2d_capi.hip']
-HEADERS = [CSRC / 'd2d_internal.h', INCLUDE / 'd2d_hip.h']
+SOURCES = ['d2d_step.hip', 'd2d_rollout.hip', 'd2d_obs.hip', 'd2d_reset.hip', 'd2d_capi.hip']
+HEADERS = [CSRC / 'd2d_internal.h', CSRC / 'd2d_step_device.h', INCLUDE / 'd2d_hip.h']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-unused-value',
          # the kernels already issue their uniform-address LDS atomics from one lane (or on rare paths): LLVM's atomic optimizer
          # only wraps them in mbcnt / readlane / popcount-multiply sequences

@@ -6,10 +6,13 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -71,6 +74,7 @@ struct d2d_handle {
     // device-side tables
     float4* rec = nullptr;          // per-link records: 3 rows of Nmax x 16 B (d2d_internal.h), see refresh_tables
     float2* rec_h = nullptr;        // per-link (head, tail) of -exponent / 2, see refresh_tables
+    int* rec_grp = nullptr;         // per group of 64 links: the group's record in one 64-byte row (rec_uniform only), see refresh_tables
     int* act_cols = nullptr;        // [Nmax] action column per link (arbitrary fixed sets)
     unsigned* side_words = nullptr; // [ceil(Nmax / 32)] sidelink membership bits, rebuilt with the records
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
@@ -81,6 +85,7 @@ struct d2d_handle {
     float* gain_table = nullptr;
     size_t gain_elems = 0;
     int table_per_env = 0;
+    int table_links = 0;            // > 0: gain_table is [B or 1][n][n] by (tx LINK, rx LINK) of that link list (d2d_set_path_loss_link_table)
     unsigned* status = nullptr;
     // host-side copies used to derive the device columns
     std::vector<double> eirp_off, rx_off, noise, sens, bw, a_tx, a_rx, expo;
@@ -194,7 +199,11 @@ int refresh_tables(d2d_handle* h) {
         // action decode by multiply-high: M = ceil(2^32 / P) is exact for act < 2^32 / P (error term M P - 2^32 < P); the
         // bound travels with it, capped at 2^24 - 1 (q * P then fits the 24-bit multiplier).  P < 2: hardware divide.
         const uint32_t M = P >= 2 ? (uint32_t)(((1ull << 32) + P - 1) / P) : 0u;
-        const uint32_t lim = P >= 2 ? (uint32_t)std::min<uint64_t>(0xFFFFFFFFull / P, (1u << 24) - 1) : 0u;
+        // ... and at R * P - 1, the largest action that names an RB inside [0, R): the rollout kernel (d2d_rollout.hip) tests
+        // `act <= bound` once and then knows both that the multiply-high quotient is exact and that it is a valid RB; an action
+        // beyond the bound takes the division arm everywhere, which is exact for any value
+        const uint32_t lim = P >= 2 ? (uint32_t)std::min<uint64_t>(std::min<uint64_t>(0xFFFFFFFFull / P, (1u << 24) - 1),
+                                                                   (uint64_t)h->cfg.num_rbs * P - 1) : 0u;
         ra[4 * i + 2] = fixed ? h->fixed_rb[i] : (int32_t)M;
         ra[4 * i + 3] = fixed ? h->fixed_pwr[i] : (int32_t)lim;
         if (fixed != (i < h->n_fixed)) prefix = false;
@@ -253,6 +262,20 @@ int refresh_tables(d2d_handle* h) {
         uint32_t pi, pg;
         std::memcpy(&pi, &rc[4 * i + 3], 4); std::memcpy(&pg, &rc[4 * g + 3], 4);
         uniform = uniform && (pi & 0xFFFFu) == (pg & 0xFFFFu) && rech[2 * i] == rech[2 * g] && rech[2 * i + 1] == rech[2 * g + 1];
+    }
+    if (uniform) {
+        // ... and the rollout kernel takes a group's whole record with ONE s_load_dwordx16 from a 64-byte row
+        std::vector<int32_t> grp((size_t)(N / 64) * 16, 0);
+        for (int g = 0; g < N / 64; ++g) {
+            const int i = g * 64;
+            int32_t* row = grp.data() + (size_t)g * 16;
+            row[0] = ra[4 * i + 2]; row[1] = ra[4 * i + 3]; row[2] = ra[4 * i] & ~D2D_REC_TXDEV_MASK; row[3] = 0;
+            std::memcpy(row + 4, &rb[4 * i], 16);
+            std::memcpy(row + 8, &rc[4 * i], 16);
+            std::memcpy(row + 12, &rech[2 * i], 8);
+        }
+        HIP_TRY(hipMemcpyAsync(h->rec_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->rec_uniform = uniform;
     h->tables_dirty = false;
@@ -519,11 +542,14 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.rec_b = h->rec + S;
     s.rec_c = h->rec + 2 * (size_t)S;
     s.rec_h = h->rec_h;
+    s.rec_grp = h->rec_grp;
     s.lpos = h->lpos;
     s.act_cols = h->act_cols;
     s.side_words = h->side_words;
     s.gain_table = h->gain_table;
-    s.table_env_stride = h->table_per_env ? (long long)D * D : 0;
+    s.table_by_link = h->table_links > 0;
+    s.table_pitch = h->table_links > 0 ? h->table_links : D;
+    s.table_env_stride = h->table_per_env ? (long long)s.table_pitch * s.table_pitch : 0;
     s.env_offset = h->env_offset;
     if (h->mode == d2d::PL_SHADOW) {
         s.shadow_chi = (float)h->shadow_chi;
@@ -591,6 +617,18 @@ int rccl_fail(const char* what, int code) {
                                  " (" + std::to_string(code) + ")");
 }
 
+// No C++ exception crosses the C ABI (Errors: the reference raises Python exceptions only - d2d_env.py:100,
+// simulator.py:56,74 - and a C or ctypes caller cannot catch ours): every entry point below is a function-try-block whose
+// handlers turn std::bad_alloc (host vectors sized by caller input) into D2D_ERR_NO_MEMORY and anything else into D2D_ERR_STATE.
+int caught(int code, const char* what) noexcept {
+    try { g_last_error = what; } catch (...) { }         // the message itself may not fit: the code still goes back
+    return code;
+}
+#define D2D_CATCH                                                                                          \
+    catch (const std::bad_alloc&) { return caught(D2D_ERR_NO_MEMORY, "out of host memory"); }              \
+    catch (const std::exception& e) { return caught(D2D_ERR_STATE, e.what()); }                            \
+    catch (...) { return caught(D2D_ERR_STATE, "unknown C++ exception"); }
+
 }  // namespace
 
 extern "C" {
@@ -599,7 +637,7 @@ int d2d_abi_version(void) { return D2D_ABI_VERSION; }
 
 const char* d2d_last_error(void) { return g_last_error.c_str(); }
 
-int d2d_create(const d2d_config* cfg, d2d_handle** out) {
+int d2d_create(const d2d_config* cfg, d2d_handle** out) try {
     if (!cfg || !out) return fail(D2D_ERR_INVALID, "null argument");
     *out = nullptr;
     if (cfg->abi_version != D2D_ABI_VERSION) return fail(D2D_ERR_INVALID, "abi_version mismatch");
@@ -643,6 +681,7 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
     h->stream = h->own_stream;
     CREATE_TRY(hipMalloc(&h->rec, (size_t)3 * h->Nmax * 16));
     CREATE_TRY(hipMalloc(&h->rec_h, (size_t)h->Nmax * 8));
+    CREATE_TRY(hipMalloc(&h->rec_grp, ((size_t)h->Nmax / 64 + 1) * 64));
     CREATE_TRY(hipMalloc(&h->lpos, (size_t)h->B * h->Nmax * 16));
     CREATE_TRY(hipMalloc(&h->act_cols, (size_t)h->Nmax * 4));
     CREATE_TRY(hipMalloc(&h->side_words, ((size_t)(h->Nmax + 31) / 32 + 1) * 4));
@@ -651,9 +690,9 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) {
 #undef CREATE_TRY
     *out = h;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_destroy(d2d_handle* h) {
+int d2d_destroy(d2d_handle* h) try {
     if (!h) return D2D_OK;
     DeviceGuard device_guard_(h->cfg.device_ordinal);
     if (h->stream) hipStreamSynchronize(h->stream);
@@ -666,6 +705,7 @@ int d2d_destroy(d2d_handle* h) {
         if (bf.ptr && bf.owned) hipFree(bf.ptr);
     if (h->rec) hipFree(h->rec);
     if (h->rec_h) hipFree(h->rec_h);
+    if (h->rec_grp) hipFree(h->rec_grp);
     if (h->lpos) hipFree(h->lpos);
     if (h->dbg) hipFree(h->dbg);
     if (h->act_cols) hipFree(h->act_cols);
@@ -681,9 +721,9 @@ int d2d_destroy(d2d_handle* h) {
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_stream(d2d_handle* h, void* hip_stream) {
+int d2d_set_stream(d2d_handle* h, void* hip_stream) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -691,17 +731,17 @@ int d2d_set_stream(d2d_handle* h, void* hip_stream) {
     // enqueued there is ordered with the caller's own kernels and copies.  Only the sentinel selects the private one.
     h->stream = hip_stream == D2D_STREAM_PRIVATE ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_synchronize(d2d_handle* h) {
+int d2d_synchronize(d2d_handle* h) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return D2D_OK;
-}
+} D2D_CATCH
 
 int d2d_set_device_table(d2d_handle* h, int32_t n_dev, const double* eirp_off_db, const double* rx_off_db,
-                         const double* noise_dbm, const double* sens_dbm, const double* bw_hz) {
+                         const double* noise_dbm, const double* sens_dbm, const double* bw_hz) try {
     if (!h || !eirp_off_db || !rx_off_db || !noise_dbm || !sens_dbm || !bw_hz) return fail(D2D_ERR_INVALID, "null argument");
     if (n_dev != h->D) return fail(D2D_ERR_INVALID, "n_dev must be 1 + num_cues + 2*num_due_pairs = " + std::to_string(h->D));
     h->eirp_off.assign(eirp_off_db, eirp_off_db + n_dev);
@@ -711,10 +751,10 @@ int d2d_set_device_table(d2d_handle* h, int32_t n_dev, const double* eirp_off_db
     h->bw.assign(bw_hz, bw_hz + n_dev);
     h->have_dev = true; h->tables_dirty = true;
     return D2D_OK;
-}
+} D2D_CATCH
 
 int d2d_set_path_loss_power_law(d2d_handle* h, int32_t n_dev, const double* a_tx_db, const double* a_rx_db,
-                                const double* exponent) {
+                                const double* exponent) try {
     if (!h || !a_tx_db || !a_rx_db || !exponent) return fail(D2D_ERR_INVALID, "null argument");
     if (n_dev != h->D) return fail(D2D_ERR_INVALID, "n_dev must be " + std::to_string(h->D));
     for (int d = 0; d < n_dev; ++d)
@@ -726,26 +766,24 @@ int d2d_set_path_loss_power_law(d2d_handle* h, int32_t n_dev, const double* a_tx
     h->mode = d2d::PL_POWER;   // refined to PL_INV_SQUARE in refresh_tables when every exponent is 2
     h->have_pl = true; h->tables_dirty = true;
     return D2D_OK;
-}
+} D2D_CATCH
 
 int d2d_set_path_loss_shadowing(d2d_handle* h, int32_t n_dev, const double* a_tx_db, const double* a_rx_db,
-                                const double* exponent, double d0_m, double chi_db, uint64_t seed) {
+                                const double* exponent, double d0_m, double chi_db, uint64_t seed) try {
     if (!(d0_m >= 0.0) || !(chi_db >= 0.0)) return fail(D2D_ERR_INVALID, "d0_m and chi_db must be >= 0");
     int rc = d2d_set_path_loss_power_law(h, n_dev, a_tx_db, a_rx_db, exponent);
     if (rc) return rc;
     h->mode = d2d::PL_SHADOW;
     h->shadow_d0 = d0_m; h->shadow_chi = chi_db; h->shadow_seed = seed; h->shadow_step = 0;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env) {
-    if (!h || !pl_db) return fail(D2D_ERR_INVALID, "null argument");
-    USE_DEVICE(h);
-    const size_t elems = (size_t)h->D * h->D * (per_env ? (size_t)h->B : 1);
-    // dB -> linear gain in DOUBLE, rounded once: a float32 dB value is off by up to 3.8e-6 dB near 100 dB, which alone is
-    // most of the 1e-5 bar (ABI 2 took floats: worst case 7.3e-6 of the SINR)
-    std::vector<float> lin(elems);
-    for (size_t k = 0; k < elems; ++k) lin[k] = (float)std::pow(10.0, -pl_db[k] / 10.0);
+namespace {
+// dB -> linear gain (in DOUBLE, rounded once: a float32 dB value is off by up to 3.8e-6 dB near 100 dB, which alone is most of
+// the 1e-5 bar) of `elems` table entries into the handle's device table, through two pinned staging blocks of at most 1 Mi
+// floats each: the host never holds a second copy of the caller's table (9.7 GB for a per-env table at BASELINE config 3
+// sizes before round 5), and the conversion of one chunk overlaps the copy of the other.
+int upload_gain_table(d2d_handle* h, const double* pl_db, size_t elems) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->gain_elems < elems) {
         if (h->gain_table) HIP_TRY(hipFree(h->gain_table));
@@ -753,14 +791,64 @@ int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env)
         HIP_TRY(hipMalloc(&h->gain_table, elems * 4));
         h->gain_elems = elems;
     }
-    HIP_TRY(hipMemcpy(h->gain_table, lin.data(), elems * 4, hipMemcpyHostToDevice));
+    const size_t chunk = std::min<size_t>(elems, (size_t)1 << 20);
+    float* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t err = hipSuccess;
+    for (int k = 0; k < 2 && err == hipSuccess; ++k) {
+        err = hipHostMalloc(reinterpret_cast<void**>(&stage[k]), chunk * 4, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+    }
+    size_t at = 0;
+    for (int c = 0; at < elems && err == hipSuccess; ++c) {
+        const int k = c & 1;
+        const size_t n = std::min(chunk, elems - at);
+        if (c >= 2) err = hipEventSynchronize(done[k]);                // the copy that last read this block has finished
+        if (err != hipSuccess) break;
+        for (size_t e = 0; e < n; ++e) stage[k][e] = (float)std::pow(10.0, -pl_db[at + e] / 10.0);
+        err = hipMemcpyAsync(h->gain_table + at, stage[k], n * 4, hipMemcpyHostToDevice, h->stream);
+        if (err == hipSuccess) err = hipEventRecord(done[k], h->stream);
+        at += n;
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
+    for (int k = 0; k < 2; ++k) {                                       // every exit releases what was allocated
+        if (done[k]) (void)hipEventDestroy(done[k]);
+        if (stage[k]) (void)hipHostFree(stage[k]);
+    }
+    if (err != hipSuccess) return fail(D2D_ERR_HIP, std::string("path-loss table upload: ") + hipGetErrorString(err));
+    return D2D_OK;
+}
+}  // namespace
+
+int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env) try {
+    if (!h || !pl_db) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
+    const size_t elems = (size_t)h->D * h->D * (per_env ? (size_t)h->B : 1);
+    int rc = upload_gain_table(h, pl_db, elems);
+    if (rc) return rc;
     h->table_per_env = per_env ? 1 : 0;
+    h->table_links = 0;
     h->mode = d2d::PL_TABLE;
     h->have_pl = true; h->tables_dirty = true;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const int32_t* rx_dev, const int32_t* link_type) {
+int d2d_set_path_loss_link_table(d2d_handle* h, const double* pl_db, int32_t n_links, int32_t per_env) try {
+    if (!h || !pl_db) return fail(D2D_ERR_INVALID, "null argument");
+    USE_DEVICE(h);
+    if (!h->have_links) return fail(D2D_ERR_STATE, "d2d_set_links first: the table is indexed by its link list");
+    if (n_links != h->N || n_links < 1) return fail(D2D_ERR_INVALID, "n_links must be the length of the current link list (" + std::to_string(h->N) + ")");
+    const size_t elems = (size_t)n_links * n_links * (per_env ? (size_t)h->B : 1);
+    int rc = upload_gain_table(h, pl_db, elems);
+    if (rc) return rc;
+    h->table_per_env = per_env ? 1 : 0;
+    h->table_links = n_links;
+    h->mode = d2d::PL_TABLE;
+    h->have_pl = true; h->tables_dirty = true;
+    return D2D_OK;
+} D2D_CATCH
+
+int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const int32_t* rx_dev, const int32_t* link_type) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (n_links < 0 || n_links > h->Nmax) return fail(D2D_ERR_INVALID, "n_links must be in [0, max_links]");
@@ -782,10 +870,14 @@ int d2d_set_links(d2d_handle* h, int32_t n_links, const int32_t* tx_dev, const i
     h->tables_dirty = true;          // the per-link records follow the link table (uploaded by the next step)
     h->lpos_dirty = true;
     h->have_links = true;
+    if (h->table_links) {            // a table indexed by the OLD link list: gone with it
+        h->table_links = 0;
+        if (h->mode == d2d::PL_TABLE) h->have_pl = false;
+    }
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_idx, const int32_t* rb, const int32_t* pwr_dbm) {
+int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_idx, const int32_t* rb, const int32_t* pwr_dbm) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     if (!h->have_links) return fail(D2D_ERR_STATE, "d2d_set_links first: fixed actions refer to its link list");
     if (n_fixed < 0 || n_fixed > h->N) return fail(D2D_ERR_INVALID, "n_fixed must be in [0, n_links]");
@@ -802,30 +894,30 @@ int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_id
     h->n_fixed = n_fixed;
     h->tables_dirty = true;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_positions_changed(d2d_handle* h) {
+int d2d_positions_changed(d2d_handle* h) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     h->lpos_dirty = true;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param) {
+int d2d_set_reward(d2d_handle* h, int32_t reward_fn, float param) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (reward_fn < D2D_REWARD_NONE || reward_fn > D2D_REWARD_CUE_SINR_SHANNON) return fail(D2D_ERR_INVALID, "unknown reward_fn");
     h->reward_fn = reward_fn; h->reward_param = param;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_reward_layout(d2d_handle* h, int32_t layout) {
+int d2d_set_reward_layout(d2d_handle* h, int32_t layout) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     if (layout != D2D_REWARD_PER_AGENT && layout != D2D_REWARD_PER_ENV) return fail(D2D_ERR_INVALID, "unknown reward layout");
     h->reward_layout = layout;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_obs_dtype(d2d_handle* h, int32_t dtype) {
+int d2d_set_obs_dtype(d2d_handle* h, int32_t dtype) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     if (dtype != D2D_F32 && dtype != D2D_F64) return fail(D2D_ERR_INVALID, "obs dtype must be D2D_F32 or D2D_F64");
     USE_DEVICE(h);
@@ -835,41 +927,41 @@ int d2d_set_obs_dtype(d2d_handle* h, int32_t dtype) {
     }
     h->obs_f64 = dtype == D2D_F64;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode) {
+int d2d_set_obs_mode(d2d_handle* h, int32_t obs_mode) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (obs_mode < D2D_OBS_NONE || obs_mode > D2D_OBS_LINEAR) return fail(D2D_ERR_INVALID, "unknown obs_mode");
     h->obs_mode = obs_mode;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_export_actions(d2d_handle* h, int32_t enabled) {
+int d2d_set_export_actions(d2d_handle* h, int32_t enabled) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     h->export_actions = enabled ? 1 : 0;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_bucketing(d2d_handle* h, int32_t enabled) {
+int d2d_set_bucketing(d2d_handle* h, int32_t enabled) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     h->bucketing = enabled ? 1 : 0;
     return D2D_OK;
-}
+} D2D_CATCH
 
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
 // diagnostic builds only (not in include/d2d_hip.h): copy the phase stamps of the last step to the host
-extern "C" int d2d_debug_stamps(d2d_handle* h, void* host, size_t bytes) {
+extern "C" int d2d_debug_stamps(d2d_handle* h, void* host, size_t bytes) try {
     if (!h || !h->dbg) return fail(D2D_ERR_STATE, "no stamps: set D2D_TUNE_STEP_ABLATE bit 8192 and step first");
     USE_DEVICE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(host, h->dbg, bytes, hipMemcpyDeviceToHost));
     return D2D_OK;
-}
+} D2D_CATCH
 #endif
 
-int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
+int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     switch (key) {
@@ -939,9 +1031,9 @@ int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) {
         default: return fail(D2D_ERR_INVALID, "unknown tuning key");
     }
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes) {
+int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes) try {
     if (!h || !dev_ptr) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
@@ -964,9 +1056,9 @@ int d2d_get_buffer(d2d_handle* h, int32_t which, void** dev_ptr, size_t* bytes) 
     if (rc) return rc;
     if (bytes) *bytes = active_bytes(h, which, h->N ? h->N : h->Nmax);
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
+int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
@@ -980,9 +1072,9 @@ int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) {
         h->lpos_dirty = true;
     }
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes, size_t dst_offset) {
+int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes, size_t dst_offset) try {
     if (!h || !host_src) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
@@ -998,9 +1090,9 @@ int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes,
         h->lpos_dirty = true;
     }
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset) {
+int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset) try {
     if (!h || !host_dst) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     if (which < 0 || which >= D2D_BUF_COUNT) return fail(D2D_ERR_INVALID, "unknown buffer");
@@ -1016,25 +1108,25 @@ int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, siz
     HIP_TRY(hipMemcpyAsync(host_dst, static_cast<const char*>(bf.ptr) + src_offset, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_set_positions(d2d_handle* h, const float* x, const float* y, int32_t env_begin, int32_t env_count) {
+int d2d_set_positions(d2d_handle* h, const float* x, const float* y, int32_t env_begin, int32_t env_count) try {
     if (!h || !x || !y) return fail(D2D_ERR_INVALID, "null argument");
     if (env_begin < 0 || env_count < 0 || env_begin + env_count > h->B) return fail(D2D_ERR_INVALID, "env range out of bounds");
     const size_t off = (size_t)env_begin * h->D * 4, bytes = (size_t)env_count * h->D * 4;
     int rc = d2d_upload(h, D2D_BUF_POS_X, x, bytes, off);
     if (rc) return rc;
     return d2d_upload(h, D2D_BUF_POS_Y, y, bytes, off);
-}
+} D2D_CATCH
 
-int d2d_set_env_offset(d2d_handle* h, uint64_t first_env) {
+int d2d_set_env_offset(d2d_handle* h, uint64_t first_env) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     h->env_offset = first_env;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const uint8_t* fixed_mask, const float* fixed_xy) {
+int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const uint8_t* fixed_mask, const float* fixed_xy) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if ((fixed_mask == nullptr) != (fixed_xy == nullptr)) return fail(D2D_ERR_INVALID, "fixed_mask and fixed_xy go together");
@@ -1064,25 +1156,25 @@ int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const ui
     h->have_pos = true;
     h->lpos_dirty = !rows_here;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_step(d2d_handle* h, const int32_t* actions_dev) {
+int d2d_step(d2d_handle* h, const int32_t* actions_dev) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (!actions_dev && !h->buf[D2D_BUF_ACTIONS].ptr && (h->N == 0 || h->n_fixed < h->N))
         return fail(D2D_ERR_STATE, "no actions: pass a pointer or fill D2D_BUF_ACTIONS");
     return run_step(h, 0, actions_dev, nullptr, nullptr);
-}
+} D2D_CATCH
 
-int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev) {
+int d2d_step_rb_pwr(d2d_handle* h, const int32_t* rb_dev, const int32_t* pwr_dev) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if ((!rb_dev && !h->buf[D2D_BUF_RB].ptr) || (!pwr_dev && !h->buf[D2D_BUF_PWR].ptr))
         return fail(D2D_ERR_STATE, "no rb/pwr: pass pointers or fill D2D_BUF_RB / D2D_BUF_PWR");
     return run_step(h, 1, rb_dev, pwr_dev, nullptr);
-}
+} D2D_CATCH
 
-int d2d_expand_table(d2d_handle* h, const float* table_dev, int32_t n_envs, int32_t n_links, float* obs_dev) {
+int d2d_expand_table(d2d_handle* h, const float* table_dev, int32_t n_envs, int32_t n_links, float* obs_dev) try {
     if (!h || !table_dev || !obs_dev) return fail(D2D_ERR_INVALID, "null argument");
     if (n_envs < 1 || n_links < 1 || n_links > D2D_MAX_LINKS) return fail(D2D_ERR_INVALID, "n_envs >= 1 and 1 <= n_links <= D2D_MAX_LINKS");
     USE_DEVICE(h);
@@ -1094,9 +1186,9 @@ int d2d_expand_table(d2d_handle* h, const float* table_dev, int32_t n_envs, int3
     HIP_TRY(d2d::launch_obs_expand(o, h->stream));
     if (ep) HIP_TRY(hipEventRecord(ep->stop, h->stream));
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_step_host(d2d_handle* h, const int32_t* rb_host, const int32_t* pwr_host, const void** out_host, d2d_host_layout* layout) {
+int d2d_step_host(d2d_handle* h, const int32_t* rb_host, const int32_t* pwr_host, const void** out_host, d2d_host_layout* layout) try {
     if (!h || !rb_host || !pwr_host || !out_host || !layout) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     if (!h->have_links) return fail(D2D_ERR_STATE, "d2d_set_links has not been called");
@@ -1150,17 +1242,17 @@ int d2d_step_host(d2d_handle* h, const int32_t* rb_host, const int32_t* pwr_host
     *out_host = h->host_out_pinned;
     *layout = L;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_comm_unique_id(void* id_out) {
+int d2d_comm_unique_id(void* id_out) try {
     if (!id_out) return fail(D2D_ERR_INVALID, "null argument");
     int rc = load_rccl();
     if (rc) return rc;
     const int e = g_rccl.GetUniqueId(id_out);
     return e ? rccl_fail("ncclGetUniqueId", e) : D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_comm_init(d2d_handle* h, int32_t world_size, int32_t rank, const void* unique_id) {
+int d2d_comm_init(d2d_handle* h, int32_t world_size, int32_t rank, const void* unique_id) try {
     if (!h || !unique_id) return fail(D2D_ERR_INVALID, "null argument");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(D2D_ERR_INVALID, "rank must be in [0, world_size)");
     USE_DEVICE(h);
@@ -1179,9 +1271,9 @@ int d2d_comm_init(d2d_handle* h, int32_t world_size, int32_t rank, const void* u
     if (e) { h->comm = nullptr; return rccl_fail("ncclCommInitRank", e); }
     h->comm_world = world_size; h->comm_rank = rank;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_comm_destroy(d2d_handle* h) {
+int d2d_comm_destroy(d2d_handle* h) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     if (h->comm) {
@@ -1190,9 +1282,9 @@ int d2d_comm_destroy(d2d_handle* h) {
         h->comm = nullptr; h->comm_used = false;
     }
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_allgather(d2d_handle* h, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* hip_stream) {
+int d2d_allgather(d2d_handle* h, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* hip_stream) try {
     if (!h || !send_dev || !recv_dev) return fail(D2D_ERR_INVALID, "null argument");
     if (!h->comm) return fail(D2D_ERR_STATE, "d2d_comm_init has not been called");
     USE_DEVICE(h);
@@ -1200,9 +1292,9 @@ int d2d_allgather(d2d_handle* h, const void* send_dev, void* recv_dev, size_t by
     h->comm_used = true;
     const int e = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, /* ncclInt8 */ 0, h->comm, stream);
     return e ? rccl_fail("ncclAllGather", e) : D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_status_flags(d2d_handle* h, uint32_t* flags) {
+int d2d_status_flags(d2d_handle* h, uint32_t* flags) try {
     if (!h || !flags) return fail(D2D_ERR_INVALID, "null argument");
     USE_DEVICE(h);
     if (!h->buf[D2D_BUF_ENV_FLAGS].ptr) { *flags = 0; return D2D_OK; }
@@ -1210,18 +1302,18 @@ int d2d_status_flags(d2d_handle* h, uint32_t* flags) {
     HIP_TRY(hipMemcpyAsync(flags, h->status, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_profile_enable(d2d_handle* h, int32_t enabled) {
+int d2d_profile_enable(d2d_handle* h, int32_t enabled) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     int rc = drain_events(h);
     if (rc) return rc;
     h->prof = enabled != 0;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
+int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* launches) try {
     if (!h || kernel < 0 || kernel > 1) return fail(D2D_ERR_INVALID, "bad argument");
     USE_DEVICE(h);
     int rc = drain_events(h);
@@ -1229,20 +1321,20 @@ int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* l
     if (total_ms) *total_ms = h->acc_ms[kernel];
     if (launches) *launches = h->launches[kernel];
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_profile_reset(d2d_handle* h) {
+int d2d_profile_reset(d2d_handle* h) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
     int rc = drain_events(h);
     if (rc) return rc;
     h->acc_ms[0] = h->acc_ms[1] = 0; h->launches[0] = h->launches[1] = 0;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s) {
+int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s) try {
     return d2d_probe_write_variants(h, bytes, iters, gb_per_s, nullptr, 0);
-}
+} D2D_CATCH
 
 namespace {
 // one variant of the fill family over `dst`: GB/s sustained over `iters` launches behind one warm-up launch
@@ -1270,7 +1362,7 @@ int time_fill(d2d_handle* h, float* dst, size_t bytes, const float* src, int var
 }
 }  // namespace
 
-int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s, double* per_variant, int32_t n) {
+int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s, double* per_variant, int32_t n) try {
     if (!h || !best_gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
     if (n < 0 || (n > 0 && !per_variant)) return fail(D2D_ERR_INVALID, "bad argument");
     const size_t group = (size_t)8 * 512 * 1024 * 16;         // whole groups of 8 regions of 512 rows (64 MiB at the widest row)
@@ -1296,9 +1388,9 @@ int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double*
     if (rc) return rc;
     *best_gb_per_s = best;
     return D2D_OK;
-}
+} D2D_CATCH
 
-int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters, double* gb_per_s) {
+int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters, double* gb_per_s) try {
     if (!h || !gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
     if (variant < 0 || variant >= 5 * 4 * d2d::fill_variants()) return fail(D2D_ERR_INVALID, "variant must be in [0, 640)");
     if (stagger < 0 || stagger > 64) return fail(D2D_ERR_INVALID, "stagger must be in [0, 64]");
@@ -1321,6 +1413,6 @@ int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t v
     if (src) (void)hipFree(src);
     if (!dst_dev && tmp) (void)hipFree(tmp);
     return rc;
-}
+} D2D_CATCH
 
 }  // extern "C"

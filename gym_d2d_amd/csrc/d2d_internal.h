@@ -70,11 +70,15 @@ struct StepArgs {
     const float4* rec_b;     // [N]
     const float4* rec_c;     // [N]
     const float2* rec_h;     // [N] head / tail of -exponent / 2 of the link's transmitter (power-law / shadowing kernels)
+    const int* rec_grp;      // rec_uniform only: [N / 64][16 dwords] the record of every aligned group of 64 links in ONE 64-byte row -
+                             // (magic, bound, a.x, 0 | b.xyzw | c.xyzw | h.x, h.y, 0, 0): one s_load_dwordx16 per wave (rollout kernel)
     const int* act_cols;     // [N] action column of every link (col_mode 1 only; 0 for fixed links)
     const unsigned* side_words;  // [ceil(N / 32)] bit i set <=> link i is a sidelink (host-built with the records)
     const float4* lpos;      // [B, N] (tx_x, tx_y, rx_x, rx_y) of every link, rebuilt when positions / links change
-    const float* gain_table; // PL_TABLE: linear gain [D,D] (tx major)
-    long long table_env_stride; // 0 or D*D
+    const float* gain_table; // PL_TABLE: linear gain, tx major: [D,D] by (tx device, rx device), or [N,N] by (tx link, rx link)
+    long long table_env_stride; // 0 or pitch * pitch
+    int table_by_link;       // rows / columns are link indices (d2d_set_path_loss_link_table), else device indices
+    int table_pitch;         // row length: N or D
     // PL_SHADOW (ShadowingPathLoss, path_loss.py:69-81)
     float shadow_chi;        // std of the shadowing term, dB
     float shadow_d0sq;       // (close-in reference distance)^2
@@ -112,6 +116,7 @@ struct ObsArgs {
 };
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
+hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, size_t lds, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written,
                        const float* src = nullptr, int stagger = 0);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 3      /* 3: double path-loss tables, per-env reward, link-position rows, f64 obs, staged write probe */
+#define D2D_ABI_VERSION 4      /* 4: D2D_ERR_NO_MEMORY, link-indexed path-loss table, measurement probes moved out (d2d_hip_diag.h) */
 #define D2D_MAX_LINKS 2048      /* links per env the step kernel's LDS staging is sized for */
 #define D2D_UNIQUE_ID_BYTES 128 /* size of an RCCL unique id (ncclUniqueId)                  */
 
@@ -35,8 +35,11 @@ typedef enum d2d_status {
     D2D_OK = 0,
     D2D_ERR_INVALID = 1,        /* bad argument / inconsistent sizes                        */
     D2D_ERR_HIP = 2,            /* a HIP runtime call failed (text in d2d_last_error)       */
-    D2D_ERR_STATE = 3,          /* call order: tables / links / positions not set yet       */
-    D2D_ERR_UNSUPPORTED = 4
+    D2D_ERR_STATE = 3,          /* call order: tables / links / positions not set yet; also any
+                                   C++ exception other than bad_alloc caught at the boundary */
+    D2D_ERR_UNSUPPORTED = 4,
+    D2D_ERR_NO_MEMORY = 5       /* host allocation failed (std::bad_alloc caught at the boundary:
+                                   no C++ exception ever crosses this ABI)                    */
 } d2d_status;
 
 /* link_type.py:4-7 */
@@ -145,9 +148,16 @@ int d2d_set_path_loss_shadowing(d2d_handle* h, int32_t n_dev, const double* a_tx
 /* PathLoss plugin, table route for arbitrary Python subclasses (path_loss.py:12-25;
  * examples/custom_path_loss.py:8-16): pl_db[(e,) tx_dev, rx_dev] evaluated on the host once per
  * episode.  per_env = 0: one [D,D] table shared by all envs; 1: [B,D,D].  float64 dB in (as the plugin
- * returns them), converted to linear gains in double and rounded once; entries of pairs that no link
- * uses may hold anything (NaN included) - only (tx of link j, rx of link i) pairs are ever read.       */
+ * returns them), converted to linear gains in double and rounded once, chunk by chunk through a bounded
+ * pinned staging block (the library never holds a second copy of the table on the host); entries of pairs
+ * that no link uses may hold anything (NaN included) - only (tx of link j, rx of link i) pairs are read. */
 int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env);
+/* The same route without the dense device cube: pl_db[(e,) j, i] = PathLoss(tx of link j, rx of link i) for
+ * the CURRENT link list (n_links = its length) - exactly the pairs the step reads (simulator.py:93,97-101:
+ * own link j == i, interferers j != i).  [N,N] or [B,N,N] instead of [D,D] / [B,D,D] (D = 1 + C + 2P:
+ * 4.3 GB instead of 9.7 GB per 4096 envs of 512 links).  A later d2d_set_links drops the table: the next
+ * step then fails with D2D_ERR_STATE until a path-loss model is set again.                              */
+int d2d_set_path_loss_link_table(d2d_handle* h, const double* pl_db, int32_t n_links, int32_t per_env);
 
 /* Which (tx, rx) device pairs act this step and as what (Action.tx/rx/link_type, actions.py:9-15;
  * typing rule d2d_env.py:80-91).  n_links <= max_links.  Order = agent order of the outputs.       */
@@ -192,16 +202,14 @@ int d2d_set_bucketing(d2d_handle* h, int32_t enabled);
  * d2d_step_rb_pwr (the values are the caller's) and d2d_step_host (always exported) are not affected.  */
 int d2d_set_export_actions(d2d_handle* h, int32_t enabled);
 
-/* Launch-geometry knobs (performance only, results do not change).                                 */
+/* Launch-geometry knobs (performance only, results do not change).  The A/B shapes the kernels were tuned against (other
+ * store policies, the row-aligned / unstaged expansion kernels, the flattened mask walk, wave staggering) and the ablation
+ * switch live in d2d_hip_diag.h and exist in diagnostic builds only; a release build answers them D2D_ERR_UNSUPPORTED.    */
 typedef enum d2d_tuning {
-    D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* obs rows written per workgroup; 0 = auto                       */
-    D2D_TUNE_OBS_NONTEMPORAL = 1,  /* store policy of the obs stream: 1 (default) nontemporal, 0 plain; A/B: 2 sc1, 3 sc0 sc1,
-                                      4 sc0 sc1 nt, 5 sc1 nt (the scope bits of the gfx942+ store encoding)            */
+    D2D_TUNE_OBS_ROWS_PER_WG = 0,  /* consecutive 16-KiB pieces of an env's obs block written per workgroup (1 .. 4); 0 = auto (2) */
+    D2D_TUNE_OBS_NONTEMPORAL = 1,  /* store policy of the obs stream: 1 (default) nontemporal, 0 plain                */
     D2D_TUNE_OBS_XCD_REMAP = 2,    /* 1 (default): chunks of one env share an XCD                    */
     D2D_TUNE_OBS_BLOCK = 3,        /* threads per obs workgroup; 0 = auto                            */
-    D2D_TUNE_OBS_VARIANT = 4,      /* 0 (default): flat 32 KB slabs, T staged in LDS; 1: T read from global (A/B);
-                                      3: the row-aligned kernel of rounds 1-3 (A/B)                    */
-    D2D_TUNE_OBS_STAGGER = 16,     /* A/B: wave w of an obs workgroup sleeps w * value * 64 clocks before its stores; 0 (default) off */
     D2D_TUNE_STEP_THREADS = 5,     /* threads per ENV in the step kernel; 0 = auto (one per link).  Below half the link
                                       count no link sits in registers (strided kernel) and the per-RB search
                                       structures give way to the O(N^2) sweep                              */
@@ -209,26 +217,20 @@ typedef enum d2d_tuning {
     D2D_TUNE_STEP_BLOCK = 7,       /* threads per step workgroup (>= envs * threads/env); 0 = auto   */
     D2D_TUNE_STEP_FUSE_OBS = 8,    /* LinearObs expansion inside the step launch: 1 on, 0 off,
                                       -1 = auto (on for small N, where two launches are latency bound) */
+    D2D_TUNE_STEP_WALK = 10,       /* same-RB interferer search: 0 membership masks (words / members walk), 2 per-RB member
+                                      lists (an env that puts more than 8 links on one RB falls back to the masks inside
+                                      the launch); -1 = auto                                                    */
     D2D_TUNE_STEP_PREFETCH = 11,   /* software-prefetch distance of the action rows, in envs: -1 = auto (the envs
                                       resident on the chip at once), 0 = off                                    */
     D2D_TUNE_STEP_LPT = 12,        /* links per thread held in registers: 1, 2 (half the waves per env), -1 = auto    */
-    D2D_TUNE_STEP_WALK = 10,       /* same-RB interferer search: 0 membership masks, nested walk (words / members),
-                                      1 masks, flattened walk, 2 per-RB member lists (sorted in registers by the
-                                      receiver; an env that puts more than 8 links on one RB falls back to the
-                                      masks inside the launch); -1 = auto                                     */
     D2D_TUNE_STEP_NT_RESULTS = 13, /* rollout kernel: nontemporal result stores: 1 on (ignored with LinearObs, whose
                                       expansion kernel re-reads the table behind the step), 0 / -1 off (default:
                                       no consistent gain measured)                                             */
     D2D_TUNE_STEP_SCALAR_RECORDS = 14, /* rollout kernel: link records by one scalar load per wave when every aligned
                                       group of 64 links has identical records; -1 = auto (on when legal), 0 off  */
-    D2D_TUNE_STEP_OBS_ROTATE = 15, /* fused LinearObs expansion: workgroup w starts at step (w * value) mod (its steps) of
+    D2D_TUNE_STEP_OBS_ROTATE = 15  /* fused LinearObs expansion: workgroup w starts at step (w * value) mod (its steps) of
                                       its (env, pass) store sequence and wraps, so that the concurrent stores of the
                                       resident workgroups are not one fixed stride apart; -1 = auto (29), 0 = off  */
-    D2D_TUNE_STEP_ABLATE = 9,      /* DIAGNOSTIC builds only (D2D_BUILD_DIAG=1), the one key that DOES change
-                                      results: bit mask of kernel parts to skip (1 interferer walk, 2 mask
-                                      build, 4 mask clear, 8 result stores, 16 table store, 32 rb/pwr stores,
-                                      64 pass-0/1 barriers, 128 per-env loads hit L2) so the rest can be timed
-                                      (tools/ab_step.py ablate).  Release builds refuse any value but 0.    */
 } d2d_tuning;
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value);
 
@@ -318,25 +320,6 @@ int d2d_profile_enable(d2d_handle* h, int32_t enabled);
  * accumulated device time in ms and launch count since the last reset.                             */
 int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
 int d2d_profile_reset(d2d_handle* h);
-/* Streaming-store probe: writes a scratch buffer of `bytes` (>= 64 MiB; rounded down to whole groups of
- * eight 512-row regions) `iters` times with pure fill kernels - nothing to compute - in a family of store
- * geometries that contains the obs kernel's own (768-thread workgroups, two 12-KiB rows each, XCD-grouped
- * dispatch order, nontemporal 16-byte stores) and with hipMemsetAsync, and reports the BEST sustained rate:
- * the box's write ceiling as far as this library can demonstrate one.  d2d_probe_write_variants also
- * returns the first n per-variant rates (variant v: block {768,1024,512,256}[v & 3], rows per workgroup
- * {2,4,8,32}[(v >> 2) & 3], nontemporal unless v & 16; index D2D_PROBE_VARIANTS = hipMemsetAsync).     */
-#define D2D_PROBE_VARIANTS 32
-int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s,
-                             double* per_variant, int32_t n);
-int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s);
-/* One member of the family with the obs kernel's TIMING structure added: variant = the geometry index above
- * + 32 (every workgroup first stages one row of a table through LDS behind a barrier and stores what it reads
- * back) + 64 (wave w sleeps w * stagger * 64 clocks before its first store) + 128 * k (k = 1 .. 4: the store's cache
- * policy sc1 / sc0 sc1 / sc0 sc1 nt / sc1 nt instead of nt or plain).  dst_dev = NULL writes a scratch
- * buffer of `bytes`; a device pointer writes THAT memory (e.g. the obs block itself: same pages, same
- * footprint as the kernel being explained).                                                              */
-int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters,
-                           double* gb_per_s);
 
 #ifdef __cplusplus
 }
