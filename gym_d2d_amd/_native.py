@@ -9,11 +9,11 @@ from typing import Optional
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libd2d_hip.so'
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LINKS = 2048
 
 # d2d_status
-OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_NO_MEMORY = 0, 1, 2, 3, 4, 5
 # d2d_link_type
 UPLINK, DOWNLINK, SIDELINK = 1, 2, 3
 # d2d_reward_fn
@@ -24,6 +24,7 @@ OBS_NONE, OBS_TABLE, OBS_LINEAR = 0, 1, 2
 (BUF_POS_X, BUF_POS_Y, BUF_ACTIONS, BUF_RB, BUF_PWR, BUF_SINR_DB, BUF_SNR_DB, BUF_RATE_BPS, BUF_CAPACITY,
  BUF_REWARD, BUF_OBS_TABLE, BUF_OBS, BUF_ENV_FLAGS, BUF_LINK_POS, BUF_REWARD_ENV, BUF_COUNT) = range(16)
 FLAG_ZERO_DISTANCE, FLAG_RB_OUT_OF_RANGE, FLAG_NON_FINITE = 1, 2, 4
+# d2d_tuning (TUNE_OBS_VARIANT, TUNE_STEP_ABLATE, TUNE_OBS_STAGGER: include/d2d_hip_diag.h, diagnostic builds only)
 (TUNE_OBS_ROWS_PER_WG, TUNE_OBS_NONTEMPORAL, TUNE_OBS_XCD_REMAP, TUNE_OBS_BLOCK, TUNE_OBS_VARIANT,
  TUNE_STEP_THREADS, TUNE_STEP_ENVS_PER_WG, TUNE_STEP_BLOCK, TUNE_STEP_FUSE_OBS, TUNE_STEP_ABLATE,
  TUNE_STEP_WALK, TUNE_STEP_PREFETCH, TUNE_STEP_LPT, TUNE_STEP_NT_RESULTS, TUNE_STEP_SCALAR_RECORDS,
@@ -76,6 +77,7 @@ SIGNATURES = {
     'd2d_set_device_table': (C.c_int, [_P, _I, _DP, _DP, _DP, _DP, _DP]),
     'd2d_set_path_loss_power_law': (C.c_int, [_P, _I, _DP, _DP, _DP]),
     'd2d_set_path_loss_table': (C.c_int, [_P, _DP, _I]),
+    'd2d_set_path_loss_link_table': (C.c_int, [_P, _DP, _I, _I]),
     'd2d_set_path_loss_shadowing': (C.c_int, [_P, _I, _DP, _DP, _DP, C.c_double, C.c_double, C.c_uint64]),
     'd2d_set_links': (C.c_int, [_P, _I, _IP, _IP, _IP]),
     'd2d_set_fixed_actions': (C.c_int, [_P, _I, _IP, _IP, _IP]),
@@ -106,9 +108,6 @@ SIGNATURES = {
     'd2d_profile_enable': (C.c_int, [_P, _I]),
     'd2d_profile_read': (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'd2d_profile_reset': (C.c_int, [_P]),
-    'd2d_probe_write_bandwidth': (C.c_int, [_P, C.c_size_t, _I, C.POINTER(C.c_double)]),
-    'd2d_probe_write_variants': (C.c_int, [_P, C.c_size_t, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
-    'd2d_probe_write_staged': (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -134,6 +133,8 @@ def load_library() -> C.CDLL:
 
 
 def _check(rc: int) -> None:
+    if rc == ERR_NO_MEMORY:         # std::bad_alloc caught at the C boundary
+        raise MemoryError(load_library().d2d_last_error().decode(errors='replace'))
     if rc != OK:
         raise NativeError(rc, load_library().d2d_last_error().decode(errors='replace'))
 
@@ -197,6 +198,14 @@ class Handle:
         if t.shape not in ((d, d), (self.num_envs, d, d)):
             raise ValueError(f'path-loss table must be [{d},{d}] or [{self.num_envs},{d},{d}], got {t.shape}')
         _check(self._lib.d2d_set_path_loss_table(self._h, _dptr(t), int(t.ndim == 3)))
+
+    def set_path_loss_link_table(self, pl_db: np.ndarray) -> None:
+        """pl_db[(e,) j, i] = PathLoss(tx of link j, rx of link i) of the CURRENT link list, float64 dB: [N,N] or [B,N,N]."""
+        t = np.ascontiguousarray(pl_db, dtype=np.float64)
+        n = t.shape[-1]
+        if t.shape not in ((n, n), (self.num_envs, n, n)):
+            raise ValueError(f'link path-loss table must be [N,N] or [{self.num_envs},N,N], got {t.shape}')
+        _check(self._lib.d2d_set_path_loss_link_table(self._h, _dptr(t), n, int(t.ndim == 3)))
 
     def set_links(self, tx_dev, rx_dev, link_type) -> None:
         a = [np.ascontiguousarray(c, dtype=np.int32) for c in (tx_dev, rx_dev, link_type)]
@@ -376,21 +385,3 @@ class Handle:
     def profile_reset(self) -> None:
         _check(self._lib.d2d_profile_reset(self._h))
 
-    def probe_write_variants(self, nbytes: int, iters: int = 5):
-        """(best GB/s, [per-variant GB/s ..., hipMemsetAsync]) - see d2d_probe_write_variants."""
-        n = 33
-        best, arr = C.c_double(), (C.c_double * n)()
-        _check(self._lib.d2d_probe_write_variants(self._h, nbytes, iters, C.byref(best), arr, n))
-        return best.value, list(arr)
-
-    def probe_write_bandwidth(self, nbytes: int, iters: int = 10) -> float:
-        g = C.c_double()
-        _check(self._lib.d2d_probe_write_bandwidth(self._h, nbytes, iters, C.byref(g)))
-        return g.value
-
-    def probe_write_staged(self, nbytes: int, variant: int, stagger: int = 0, iters: int = 5, dst_ptr: int = 0) -> float:
-        """GB/s of one fill variant with the obs kernel's timing structure (+32: LDS stage + barrier, +64: per-wave sleep
-        stagger); dst_ptr = 0 writes a scratch buffer, else that device memory - see d2d_probe_write_staged."""
-        g = C.c_double()
-        _check(self._lib.d2d_probe_write_staged(self._h, _P(dst_ptr or None), nbytes, variant, stagger, iters, C.byref(g)))
-        return g.value

@@ -1,7 +1,7 @@
 // C-ABI layer of libd2d_hip.so (see include/d2d_hip.h).  Owns the SoA state of B environments in HBM and
 // enqueues the step / obs kernels on one HIP stream.  No exceptions cross the boundary; no CPU fallback exists:
 // if HIP is unusable every call fails with D2D_ERR_HIP.
-#include "../../include/d2d_hip.h"
+#include "../../include/d2d_hip_diag.h"
 #include "d2d_internal.h"
 
 #include <dlfcn.h>
@@ -13,6 +13,7 @@
 #include <cstring>
 #include <exception>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -375,7 +376,9 @@ void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float*
     o.xcd_remap = (h->tune_xcd > 0 && B % (8 * h->tune_xcd) == 0) ? h->tune_xcd : 0;   // envs interleaved per XCD
     o.nontemporal = h->tune_nt;
     o.block = block;
-    o.variant = flat ? 2 : h->tune_variant;
+    // tune_variant 2 names the flat kernel, whose grid is sized in flat chunks: when the flat shape does not apply (8-byte rows, a
+    // float64 block's float32 consumers) the row-aligned default runs on the row-aligned geometry computed above
+    o.variant = flat ? 2 : (h->tune_variant == 2 ? 0 : h->tune_variant);
     o.stagger = h->tune_stagger;
     o.out_f64 = 0;
     o.table = table;
@@ -640,6 +643,11 @@ const char* d2d_last_error(void) { return g_last_error.c_str(); }
 int d2d_create(const d2d_config* cfg, d2d_handle** out) try {
     if (!cfg || !out) return fail(D2D_ERR_INVALID, "null argument");
     *out = nullptr;
+#if defined(D2D_TEST_HOOKS) && D2D_TEST_HOOKS      // tests/test_sanitizers_cpu.py only: does the function-try-block hold?
+    if (cfg->num_envs == -12345) throw std::bad_alloc();
+    if (cfg->num_envs == -12346) throw std::runtime_error("test hook");
+    if (cfg->num_envs == -12347) throw 42;
+#endif
     if (cfg->abi_version != D2D_ABI_VERSION) return fail(D2D_ERR_INVALID, "abi_version mismatch");
     if (cfg->num_envs < 1 || cfg->num_rbs < 1 || cfg->num_cues < 0 || cfg->num_due_pairs < 0)
         return fail(D2D_ERR_INVALID, "num_envs/num_rbs must be >= 1 and device counts >= 0");
@@ -964,6 +972,13 @@ extern "C" int d2d_debug_stamps(d2d_handle* h, void* host, size_t bytes) try {
 int d2d_set_tuning(d2d_handle* h, int32_t key, int32_t value) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     USE_DEVICE(h);
+#if !(defined(D2D_DIAG) && D2D_DIAG)
+    // the A/B shapes and the ablation switch of d2d_hip_diag.h exist in diagnostic builds only
+    const bool diag_key = key == D2D_TUNE_OBS_VARIANT || key == D2D_TUNE_OBS_STAGGER || key == D2D_TUNE_STEP_ABLATE;
+    const bool diag_value = (key == D2D_TUNE_OBS_NONTEMPORAL && value > 1) || (key == D2D_TUNE_STEP_WALK && value == 1);
+    if ((diag_key && value != 0) || diag_value)
+        return fail(D2D_ERR_UNSUPPORTED, "this tuning key / value needs the diagnostic build (D2D_BUILD_DIAG=1 python -m gym_d2d_amd.build; include/d2d_hip_diag.h)");
+#endif
     switch (key) {
         case D2D_TUNE_OBS_ROWS_PER_WG: h->tune_rows = value; break;
         case D2D_TUNE_OBS_NONTEMPORAL:
@@ -1330,89 +1345,6 @@ int d2d_profile_reset(d2d_handle* h) try {
     if (rc) return rc;
     h->acc_ms[0] = h->acc_ms[1] = 0; h->launches[0] = h->launches[1] = 0;
     return D2D_OK;
-} D2D_CATCH
-
-int d2d_probe_write_bandwidth(d2d_handle* h, size_t bytes, int32_t iters, double* gb_per_s) try {
-    return d2d_probe_write_variants(h, bytes, iters, gb_per_s, nullptr, 0);
-} D2D_CATCH
-
-namespace {
-// one variant of the fill family over `dst`: GB/s sustained over `iters` launches behind one warm-up launch
-int time_fill(d2d_handle* h, float* dst, size_t bytes, const float* src, int variant, int stagger, int iters, hipEvent_t e0, hipEvent_t e1,
-              double* rate) {
-    const int variants = d2d::fill_variants();
-    size_t written = bytes / 16;
-    for (int k = -1; k < iters; ++k) {                     // k == -1: warm-up / page touch
-        if (k == 0) HIP_TRY(hipEventRecord(e0, h->stream));
-        if (variant < 0) HIP_TRY(hipMemsetAsync(dst, k & 0xFF, written * 16, h->stream));     // the runtime's own fill
-        else HIP_TRY(d2d::launch_fill(dst, bytes / 16, (float)k, h->stream, variant, &written, src, stagger));
-        if (variant < 0 && k == -1) {                      // same byte count as the family's variant 0 writes
-            size_t w0 = 0;
-            HIP_TRY(d2d::launch_fill(dst, bytes / 16, 0.0f, h->stream, 0, &w0));
-            written = w0;
-        }
-    }
-    (void)variants;
-    HIP_TRY(hipEventRecord(e1, h->stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *rate = (double)(written * 16) * iters / (ms * 1e-3) / 1e9;
-    return D2D_OK;
-}
-}  // namespace
-
-int d2d_probe_write_variants(d2d_handle* h, size_t bytes, int32_t iters, double* best_gb_per_s, double* per_variant, int32_t n) try {
-    if (!h || !best_gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
-    if (n < 0 || (n > 0 && !per_variant)) return fail(D2D_ERR_INVALID, "bad argument");
-    const size_t group = (size_t)8 * 512 * 1024 * 16;         // whole groups of 8 regions of 512 rows (64 MiB at the widest row)
-    if (bytes < group) return fail(D2D_ERR_INVALID, "the probe needs at least 64 MiB");
-    USE_DEVICE(h);
-    float* tmp = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t err = hipMalloc(&tmp, bytes);
-    if (err == hipSuccess) err = hipEventCreate(&e0);
-    if (err == hipSuccess) err = hipEventCreate(&e1);
-    const int variants = d2d::fill_variants();
-    double best = 0.0;
-    int rc = err == hipSuccess ? D2D_OK : fail(D2D_ERR_HIP, std::string("d2d_probe_write_variants: ") + hipGetErrorString(err));
-    for (int v = 0; v <= variants && rc == D2D_OK; ++v) {      // v == variants: the runtime's own fill (hipMemsetAsync)
-        double rate = 0.0;
-        rc = time_fill(h, tmp, bytes, nullptr, v < variants ? v : -1, 0, iters, e0, e1, &rate);
-        if (v < n) per_variant[v] = rate;
-        if (rate > best) best = rate;
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (tmp) (void)hipFree(tmp);
-    if (rc) return rc;
-    *best_gb_per_s = best;
-    return D2D_OK;
-} D2D_CATCH
-
-int d2d_probe_write_staged(d2d_handle* h, void* dst_dev, size_t bytes, int32_t variant, int32_t stagger, int32_t iters, double* gb_per_s) try {
-    if (!h || !gb_per_s || iters < 1) return fail(D2D_ERR_INVALID, "bad argument");
-    if (variant < 0 || variant >= 5 * 4 * d2d::fill_variants()) return fail(D2D_ERR_INVALID, "variant must be in [0, 640)");
-    if (stagger < 0 || stagger > 64) return fail(D2D_ERR_INVALID, "stagger must be in [0, 64]");
-    const size_t group = (size_t)8 * 512 * 1024 * 16;
-    if (bytes < group) return fail(D2D_ERR_INVALID, "the probe needs at least 64 MiB");
-    USE_DEVICE(h);
-    // the staged forms read one 1024-float4 row per region of 512 rows: a table 1 / 512 of the destination, as in the obs kernel
-    float *tmp = static_cast<float*>(dst_dev), *src = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const size_t src_bytes = bytes / 512 + (size_t)1024 * 16;
-    hipError_t err = hipMalloc(&src, src_bytes);
-    if (err == hipSuccess && !dst_dev) err = hipMalloc(&tmp, bytes);
-    if (err == hipSuccess) err = hipMemsetAsync(src, 0, src_bytes, h->stream);
-    if (err == hipSuccess) err = hipEventCreate(&e0);
-    if (err == hipSuccess) err = hipEventCreate(&e1);
-    int rc = err == hipSuccess ? time_fill(h, tmp, bytes, src, variant, stagger, iters, e0, e1, gb_per_s)
-                               : fail(D2D_ERR_HIP, std::string("d2d_probe_write_staged: ") + hipGetErrorString(err));
-    if (e0) (void)hipEventDestroy(e0);                  // every exit releases what was allocated
-    if (e1) (void)hipEventDestroy(e1);
-    if (src) (void)hipFree(src);
-    if (!dst_dev && tmp) (void)hipFree(tmp);
-    return rc;
 } D2D_CATCH
 
 }  // extern "C"

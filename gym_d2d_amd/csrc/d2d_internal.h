@@ -118,9 +118,6 @@ struct ObsArgs {
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, size_t lds, hipStream_t stream);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
-hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written,
-                       const float* src = nullptr, int stagger = 0);
-int fill_variants();
 size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists);
 void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out);
 hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);

@@ -16,27 +16,9 @@
 //   * stores are nontemporal (written once, never re-read by this kernel);
 //   * blockIdx is remapped so the chunks of one env share an XCD (its T stays in that XCD's L2).
 #include "d2d_internal.h"
+#include "d2d_store.h"
 
 namespace d2d {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// One 16-byte store under a chosen cache policy (gfx942+ scope / streaming bits of the global_store encoding): 0 plain, 1 nt
-// (what __builtin_nontemporal_store emits), 2 sc1 (agent scope), 3 sc0 sc1 (system scope: written through), 4 sc0 sc1 nt, 5 sc1 nt.
-// The obs stream is written once and never read by the GPU again; which policy drains it fastest is measured, not assumed
-// (d2d_probe_write_staged, D2D_TUNE_OBS_NONTEMPORAL).
-template <int POLICY>
-__device__ __forceinline__ void store16(f32x4* p, f32x4 v) {
-    if (POLICY == 0) *p = v;
-    else if (POLICY == 1) __builtin_nontemporal_store(v, p);
-    // (no "memory" clobber: nothing in these kernels reads what they store, and a clobber would pin every LDS read of the next
-    // row behind the store of this one - the obs kernel with the clobber lost 13 % where the fill, which has no reads, gained 5 %)
-    else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v));
-    else if (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v));
-    else if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v));
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v));
-}
 
 // source float index inside T_flat for output column f (even) of row i
 __device__ __forceinline__ unsigned src_col(unsigned f, unsigned i) {
@@ -286,76 +268,6 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
         if (a.nontemporal) hipLaunchKernelGGL((obs_expand_kernel<2, 1>), grid, block, lds, stream, a);
         else hipLaunchKernelGGL((obs_expand_kernel<2, 0>), grid, block, lds, stream, a);
     }
-    return hipGetLastError();
-}
-
-// Streaming-store probe (d2d_probe_write_bandwidth): pure fill kernels - no table, no LDS, no source selection - in a family
-// of store geometries that contains the obs kernel's own (one thread per float4 column of a 6N-float row: 768 threads at
-// N = 512, two rows per workgroup, XCD-grouped dispatch order, nontemporal 16-byte stores).  The best of the family (and
-// of the runtime's own hipMemsetAsync) is the box's write ceiling as far as this library can demonstrate one.
-// STAGE reproduces the obs kernel's TIMING structure around the same stores: bit 0 - every workgroup first stages one row
-// (T float4, 12 KiB at 768 threads) from `src` into LDS behind a barrier and stores what it reads back from LDS; bit 1 - wave w of
-// the workgroup sleeps w * stagger x 64 clocks before its first store.  (Does the obs kernel out-write its own geometry run as
-// a plain fill - 7.19 vs 6.39 TB/s in round 3 - because its load + barrier phase spreads the waves' stores in time?)
-template <int POLICY, int STAGE>
-__global__ __launch_bounds__(1024) void fill_kernel(f32x4* dst, const f32x4* src, unsigned chunks, unsigned rows_per_wg, unsigned rows_per_env, int xcd,
-                                                    float value, int stagger) {
-    extern __shared__ __align__(16) float fill_lds[];
-    unsigned env, chunk;
-    if (xcd) {
-        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
-        chunk = rest % chunks; env = (rest / chunks) * 8u + lane8;
-    } else {
-        env = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
-    }
-    const unsigned T = blockDim.x;                             // float4 per row
-    f32x4 v = {value, value, value, value};
-    if (STAGE & 1) {
-        f32x4* l4 = reinterpret_cast<f32x4*>(fill_lds);
-        l4[threadIdx.x] = src[(size_t)env * T + threadIdx.x];
-        __syncthreads();
-        v = l4[(threadIdx.x + 1u) % T];
-    }
-    if (STAGE & 2) {
-        const int n = (int)(threadIdx.x >> 6) * stagger;
-        for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);
-    }
-    f32x4* o4 = dst + ((size_t)env * rows_per_env + (size_t)chunk * rows_per_wg) * T + threadIdx.x;
-#pragma unroll 2
-    for (unsigned i = 0; i < rows_per_wg; ++i) store16<POLICY>(o4 + (size_t)i * T, v);
-}
-
-// Variant v of the family: block in {768, 1024, 512, 256} x rows per workgroup in {2, 4, 8, 32} x {nt, plain}, XCD-grouped
-// order; v == 0 is the obs kernel's geometry.  Bits 5-6 select the staged forms above (32: LDS stage + barrier, 64: per-wave
-// sleep stagger of `stagger` x 64 clocks, 96: both); v / 128 = 1 .. 4 replaces the store's cache policy by sc1, sc0 sc1,
-// sc0 sc1 nt, sc1 nt (store16).  "Envs" are regions of 512 rows; n_float4 is rounded DOWN to whole
-// groups of 8 regions; returns the float4 actually written through *written.
-int fill_variants() { return 4 * 4 * 2; }
-
-hipError_t launch_fill(float* dst, size_t n_float4, float value, hipStream_t stream, int variant, size_t* written, const float* src, int stagger) {
-    static const unsigned blocks[4] = {768, 1024, 512, 256}, rows[4] = {2, 4, 8, 32};
-    const unsigned T = blocks[variant & 3], rows_per_wg = rows[(variant >> 2) & 3], rows_per_env = 512, chunks = rows_per_env / rows_per_wg;
-    const bool nt = ((variant >> 4) & 1) == 0;
-    const int stage = (variant >> 5) & 3;
-    const int policy = (variant >> 7) > 0 ? (variant >> 7) + 1 : (nt ? 1 : 0);
-    const size_t env_f4 = (size_t)rows_per_env * T;
-    const size_t envs = (n_float4 / env_f4) & ~(size_t)7;
-    if (written) *written = envs * env_f4;
-    if (envs == 0) return hipSuccess;
-    if ((stage & 1) && !src) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(envs * chunks)), block(T);
-    const size_t lds = (stage & 1) ? (size_t)T * 16 : 0;
-    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-#define D2D_FILL(P, ST) hipLaunchKernelGGL((fill_kernel<P, ST>), grid, block, lds, stream, d4, s4, chunks, rows_per_wg, rows_per_env, 1, value, stagger)
-#define D2D_FILL_P(P)                                                                                               \
-    switch (stage) { case 0: D2D_FILL(P, 0); break; case 1: D2D_FILL(P, 1); break; case 2: D2D_FILL(P, 2); break; default: D2D_FILL(P, 3); break; }
-    switch (policy) {
-        case 0: D2D_FILL_P(0); break; case 1: D2D_FILL_P(1); break; case 2: D2D_FILL_P(2); break;
-        case 3: D2D_FILL_P(3); break; case 4: D2D_FILL_P(4); break; default: D2D_FILL_P(5); break;
-    }
-#undef D2D_FILL_P
-#undef D2D_FILL
     return hipGetLastError();
 }
 

@@ -262,18 +262,21 @@ class StepGatherer:
         else:
             self._all_gather(self.all_ring.view(-1), ring.view(-1))
         self.reward_step = first_step
+        self.reward_valid = self.reward_every                   # a whole block (flush() lowers it for a partial one)
         self._pending = True
 
     def flush(self) -> int:
         """reward_every > 1: gather the ring as it stands when the rollout did not end on a block boundary (launches % K != 0).
-        Returns how many leading rows of the [K, B_global] block `wait()` then returns are valid (rows = launches
-        `reward_step` ... `reward_step` + valid - 1; the rest of the block is older data); 0 = nothing was pending.
-        Every rank must call it (it is a collective).  The next launch starts a new block."""
+        Returns how many rows are valid (launches `reward_step` ... `reward_step` + valid - 1); `wait()` then returns exactly
+        those rows, [valid, B_global] (`reward_valid` holds the count); 0 = nothing was pending.  A COLLECTIVE: every rank must
+        call it at the same launch count - ranks that disagree on launches % K would leave some inside the all-gather and
+        others outside it until the rank timeout.  The next launch starts a new block."""
         k = self.reward_every
         valid = self._ring_pos % k if k > 1 else 0
         if valid == 0:
             return 0
         self._gather_ring((self._ring_pos // k) % 2, self.launches - valid)
+        self.reward_valid = valid
         self._ring_pos += k - valid                             # the next launch opens the next block (slot 0, the other ring)
         return valid
 
@@ -295,7 +298,8 @@ class StepGatherer:
         self._pending = False
         if self.reward_every > 1:
             # [world, K, b_local] -> [K, B_global]: rank-major along the env axis = global env order
-            return self.all_ring.permute(1, 0, 2).reshape(self.reward_every, -1), None
+            # (after a flush(): only the rows the partial block filled - the rest of the ring holds an older block)
+            return self.all_ring.permute(1, 0, 2).reshape(self.reward_every, -1)[:getattr(self, 'reward_valid', self.reward_every)], None
         if self.mode == 'planes':
             return self.all_reward, tuple(self.all_planes)      # (sinr_dB [B_global, N], snr_dB [B_global, N])
         return self.all_reward, self.all_signal

@@ -39,7 +39,8 @@ _OUTPUTS = (('sinr_db', _native.BUF_SINR_DB), ('snr_db', _native.BUF_SNR_DB), ('
 class VecD2DEnv:
     def __init__(self, env_config: Optional[dict] = None, num_envs: Optional[int] = None, *,
                  cue_actions: str = 'agent', use_torch: Optional[bool] = None, first_env: int = 0,
-                 export_actions: bool = True, reward_per_env: bool = False, placement_trials='auto') -> None:
+                 export_actions: bool = True, reward_per_env: bool = False, placement_trials: int = 0,
+                 placement_budget_bytes: int = 1 << 30) -> None:
         """cue_actions: 'agent' - step() takes actions for CUEs and DUEs [B, C+P] (reference behaviour);
         'traffic' - CUE links follow the env's traffic model (round-robin RB at max power,
         traffic_model.py:15-22): their (rb, pwr) are constants of the kernel's link records
@@ -56,17 +57,17 @@ class VecD2DEnv:
         (reward_fn.py:42-44); step() then returns it as [B] instead of N copies [B, N] (d2d_set_reward_layout: 4 bytes per
         link and step less).  Only with the native SystemCapacity reward.
 
-        placement_trials: where the step's dominant output block sits physically decides how fast the kernel streams it - the
-        same 61 MB obs block of BASELINE config 2 runs 13.2, 13.9 or 15.1 us per step depending on the allocation it landed in,
-        and the 50 MB table of the compact-obs step at 4096 x 512 26.7 or 28.1 us, reproducibly per allocation and independent of
-        every other buffer (profiles/r4_obs_block_placement_candidates.jsonl, r4_output_placement_candidates_stress_table.jsonl;
-        TLB and L2-channel counters are equal, so it is how the block's pages spread over the memory channels).  K > 0: the
-        first reset() times a few hundred steps on up to K candidate blocks (allocated one by one behind paddings of varying
-        size - megabytes at first, GiBs from the seventh on - all held until the choice) and keeps the fastest; it stops early once a candidate is 7 % faster than the slowest
-        seen (a faster class has shown up).  About 5 ms per candidate at config 2, 8 ms at stress sizes, once per env.
-        'auto' = 24 for the obs block of the fused LinearObs step when it is 8 ... 256 MB - larger blocks average the effect out
-        (the 25.8 GB block of config 3 is one speed everywhere) - else 0; an explicit K also places the table of a compact-obs env
-        (its classes only show with fresh actions every step, which the trials do not generate: measured 25.0 us for all 24).
+        placement_trials (default 0 = off; opt-in): where the step's dominant output block sits physically decides how fast the
+        kernel streams it - the same 61 MB obs block of BASELINE config 2 runs 13.2, 13.9 or 15.1 us per step depending on the
+        allocation it landed in, reproducibly per allocation (profiles/r4_obs_block_placement_candidates.jsonl; TLB and
+        L2-channel counters are equal, so it is how the block's pages spread over the memory channels).  K > 1: the first
+        reset() times a few hundred steps on up to K candidate blocks for the fused LinearObs step's obs block (or the table of a
+        compact-obs env), allocated one by one behind paddings of 2 - 22 MB, and keeps the fastest; it stops early once a
+        candidate is 7 % faster than the slowest seen.  Bounded and private: candidates + paddings never exceed
+        placement_budget_bytes (default 1 GiB) at once, each comes from a torch MemPool of its own that is dropped with the
+        loser (nothing is released from - or left in - the caller's caching allocator: no torch.cuda.empty_cache()), and the
+        obs tensor step() returns MOVES once, at that first reset (a tensor taken from an earlier reset() of the same env does
+        not exist - the trials run inside the first).  A lottery with better odds, not a cure: off unless asked for.
 
         step()'s `dones` on the torch path is one of two preallocated CONSTANT tensors (all False / all True), shared by
         every call: treat it as read-only (clone it before an in-place update).
@@ -148,14 +149,8 @@ class VecD2DEnv:
         mode = self.obs_fn.native_mode
         fused = mode == _native.OBS_LINEAR and self.num_links <= 128 and not getattr(self, '_native_obs64', False)
         self._placement_target = ('obs', _native.BUF_OBS) if fused else (('table', _native.BUF_OBS_TABLE) if mode == _native.OBS_TABLE else None)
-        if placement_trials == 'auto':
-            nbytes = 0
-            if self.use_torch and self._placement_target is not None:
-                t = self._t[self._placement_target[0]]
-                nbytes = t.numel() * t.element_size()
-            # the table's classes only show under fresh actions per step (the trials step with the reset's own, repeated): opt-in there
-            placement_trials = 24 if (8 << 20) <= nbytes <= (256 << 20) and self._placement_target[0] == 'obs' else 0
         self._placement_trials = int(placement_trials) if self.use_torch and self._placement_target is not None else 0
+        self._placement_budget = int(placement_budget_bytes)
         self.placement = None                      # after the trials: {'buffer': ..., 'us_per_step': [...], 'chosen': k}
 
     # ------------------------------------------------------------------ buffers
@@ -196,8 +191,8 @@ class VecD2DEnv:
         self._current_stream_ptr = (lambda: raw(index)) if raw is not None else \
             (lambda: torch.cuda.current_stream(self.device).cuda_stream)
         self._follow_torch_stream()
-        # per-step constants of the torch path: the buffers never move, so the view, the info dict and the two possible
-        # `dones` vectors are built once
+        # per-step constants of the torch path: the buffers do not move (the opt-in placement trials re-bind ONE block once, inside
+        # the first reset, and drop this cache), so the view, the info dict and the two possible `dones` vectors are built once
         self._view_cache = None
         self._dones = (torch.zeros(b, dtype=torch.bool, device=dev), torch.ones(b, dtype=torch.bool, device=dev))
 
@@ -292,22 +287,30 @@ class VecD2DEnv:
         t_end = time.perf_counter() + warm_ms * 1e-3            # past the clock ramp behind the idle stretch of building the env
         while time.perf_counter() < t_end:
             timed(64)
-        cands, pads, times = [first], [], []
+        # every candidate (and the padding in front of it) lives in a MemPool of its own: dropping a loser's pool gives its memory
+        # back to the driver without touching the caching allocator the caller's tensors live in
+        def alloc_private(nbytes_, like=None):
+            pool = torch.cuda.MemPool() if hasattr(torch.cuda, 'MemPool') else None
+            if pool is None:
+                return None, (torch.empty_like(like) if like is not None else torch.empty(nbytes_, dtype=torch.uint8, device=self.device))
+            with torch.cuda.use_mem_pool(pool):
+                t = torch.empty_like(like) if like is not None else torch.empty(nbytes_, dtype=torch.uint8, device=self.device)
+            return pool, t
+        cands, pools, pads, times = [first], [None], [], []
+        held = 0
         for k in range(trials):
             if k:
-                # neighbouring allocations tend to share a speed class (runs of 3 - 9 alike among 16 consecutive candidates, whole
-                # sub-GiB regions alike in some processes): small paddings of varying size first, then, while no faster class has
-                # shown up, jumps of GiBs (the paddings are released with the losing candidates)
+                # neighbouring allocations tend to share a speed class: a padding of varying size in front of every candidate
                 pad = ((k * 7) % 11 + 1) * (2 << 20) + (k % 3) * 4096
-                if k >= 6 and k % 3 == 0:
-                    jump = (1 << 30) * (1 + 2 * (((k - 6) // 3) % 3))      # 1, 3, 5 GiB, again
-                    if torch.cuda.mem_get_info(self.device)[0] > 4 * jump + nbytes:
-                        pad = jump
+                if held + pad + nbytes > self._placement_budget:
+                    break
                 try:
-                    pads.append(torch.empty(pad, dtype=torch.uint8, device=self.device))
-                    cands.append(torch.empty_like(first))
+                    pads.append(alloc_private(pad))
+                    pool, t = alloc_private(0, like=first)
                 except torch.cuda.OutOfMemoryError:             # a crowded GPU: choose among what there is
                     break
+                cands.append(t); pools.append(pool)
+                held += pad + nbytes
             h.bind_buffer(which, cands[k].data_ptr(), nbytes)
             timed(32)
             times.append(timed(steps))
@@ -317,14 +320,14 @@ class VecD2DEnv:
         chosen = cands[best]
         h.bind_buffer(which, chosen.data_ptr(), nbytes)
         self._t[key] = chosen[:base.numel()].view(base.shape) if chosen.shape != base.shape else chosen
+        self._placement_pool = pools[best]                      # the winner's pool lives as long as the env
         h.step()                                                # the reset's step once more, into the block that stays
         self._view_cache = None
-        self.placement = {'buffer': key, 'us_per_step': [round(t, 2) for t in times], 'chosen': best}
-        if len(cands) > 1:
-            # the losing candidates and the paddings (up to a few GiB) go back to the driver, not into torch's cache
-            del cands, pads, first
-            torch.cuda.synchronize(self.device)
-            torch.cuda.empty_cache()
+        self.placement = {'buffer': key, 'us_per_step': [round(t, 2) for t in times], 'chosen': best,
+                          'transient_bytes': held, 'private_pools': pools[-1] is not None or len(pools) == 1}
+        # the losers and the paddings: tensors first, then their pools (a pool without live tensors returns its blocks to the driver)
+        torch.cuda.synchronize(self.device)
+        del cands, pads, first, base, chosen, pools
 
     def step(self, actions):
         """actions: int [B, num_agents] (torch CUDA tensor, or NumPy).  Returns (obs, rewards[B,N], dones[B], info).

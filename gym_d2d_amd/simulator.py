@@ -125,32 +125,41 @@ class Simulator:
         if not self._table_route:
             return
         self._pl_covered = None                     # positions changed: nothing evaluated for them yet
-        self._pl_positions = positions
+        # a COPY: the caller may reuse its array before a later set_links re-evaluates the table from it
+        self._pl_positions = None if positions is None else np.array(positions, dtype=np.float64, copy=True)
         if self._link_sig:
             self._evaluate_path_loss_table()
 
     def _evaluate_path_loss_table(self) -> None:
         txs, rxs = set(self.link_tx.tolist()), set(self.link_rx.tolist())
-        if self._pl_covered is not None:            # same positions, a changed link list: keep what is already there
-            if txs <= self._pl_covered[0] and rxs <= self._pl_covered[1]:
-                return
-            txs |= self._pl_covered[0]; rxs |= self._pl_covered[1]
         if self.num_envs == 1:
+            # one env: a [D,D] DEVICE table, which survives the link list changing from step to step (D2DEnv steps whatever
+            # subset of links the action dict names); same positions + a changed list: only the pairs not yet there are evaluated
+            if self._pl_covered is not None:
+                if txs <= self._pl_covered[0] and rxs <= self._pl_covered[1]:
+                    return
+                txs |= self._pl_covered[0]; rxs |= self._pl_covered[1]
             self._pl_table = self.path_loss.table_db(self._dev_list, txs, rxs)
-        else:
-            positions = self._pl_positions if self._pl_positions is not None else self.positions()
-            tables = np.empty((self.num_envs, len(self._dev_list), len(self._dev_list)), dtype=np.float64)
-            saved = [d.position for d in self._dev_list]
-            try:
-                for b in range(self.num_envs):
-                    for d, xy in zip(self._dev_list, positions[b]):
-                        d.set_position(Position(float(xy[0]), float(xy[1])))
-                    tables[b] = self.path_loss.table_db(self._dev_list, txs, rxs)
-            finally:
-                for d, p in zip(self._dev_list, saved):
-                    d.set_position(p)
-            self._pl_table = tables
-        self.handle.set_path_loss_table(self._pl_table)
+            self.handle.set_path_loss_table(self._pl_table)
+            self._pl_covered = (txs, rxs)
+            return
+        # a batch: [B,N,N] by (tx LINK, rx LINK) - exactly the pairs the step reads (d2d_set_path_loss_link_table), not the
+        # dense [B,D,D] device cube (9.7 GB at 4096 x 769 devices).  Tied to the link list: re-evaluated when it changes.
+        positions = np.array(self._pl_positions if self._pl_positions is not None else self.positions(), copy=True)
+        n = len(self.link_tx)
+        tables = np.empty((self.num_envs, n, n), dtype=np.float64)
+        pick = np.ix_(self.link_tx, self.link_rx)
+        saved = [d.position for d in self._dev_list]
+        try:
+            for b in range(self.num_envs):
+                for d, xy in zip(self._dev_list, positions[b]):
+                    d.set_position(Position(float(xy[0]), float(xy[1])))
+                tables[b] = self.path_loss.table_db(self._dev_list, txs, rxs)[pick]
+        finally:
+            for d, p in zip(self._dev_list, saved):
+                d.set_position(p)
+        self._pl_table = tables
+        self.handle.set_path_loss_link_table(tables)
         self._pl_covered = (txs, rxs)
 
     def fixed_positions(self):

@@ -40,6 +40,7 @@ int main(void) {
     EXPECT_ERR(d2d_set_path_loss_power_law(NULL, 1, one, one, one));
     EXPECT_ERR(d2d_set_path_loss_shadowing(NULL, 1, one, one, one, 1.0, 1.0, 1));
     EXPECT_ERR(d2d_set_path_loss_table(NULL, one, 0));
+    EXPECT_ERR(d2d_set_path_loss_link_table(NULL, one, 1, 0));
     EXPECT_ERR(d2d_set_links(NULL, 1, ione, ione, ione));
     EXPECT_ERR(d2d_set_fixed_actions(NULL, 1, ione, ione, ione));
     EXPECT_ERR(d2d_positions_changed(NULL));
@@ -69,9 +70,6 @@ int main(void) {
     EXPECT_ERR(d2d_profile_enable(NULL, 1));
     EXPECT_ERR(d2d_profile_read(NULL, 0, &rate, &launches));
     EXPECT_ERR(d2d_profile_reset(NULL));
-    EXPECT_ERR(d2d_probe_write_bandwidth(NULL, 1u << 26, 1, &rate));
-    EXPECT_ERR(d2d_probe_write_variants(NULL, 1u << 26, 1, &rate, NULL, 0));
-    EXPECT_ERR(d2d_probe_write_staged(NULL, NULL, 1u << 26, 0, 0, 1, &rate));
     if (d2d_destroy(NULL) != D2D_OK) { fprintf(stderr, "d2d_destroy(NULL) must be a no-op\n"); ++failures; }
 
     /* d2d_create: every field that can be wrong */
@@ -93,6 +91,16 @@ int main(void) {
     cfg = good; cfg.max_links = D2D_MAX_LINKS + 1; EXPECT_ERR(d2d_create(&cfg, &h));
     cfg = good; cfg.num_cues = 0; cfg.num_due_pairs = 0; EXPECT_ERR(d2d_create(&cfg, &h));
     cfg = good; cfg.device_ordinal = 1000; EXPECT_ERR(d2d_create(&cfg, &h));
+#ifdef D2D_TEST_HOOKS
+    /* the exception barrier (no C++ exception crosses the boundary): a library built with -DD2D_TEST_HOOKS=1
+     * throws inside d2d_create on these sentinels; what arrives here must be a status code and a message */
+    cfg = good; cfg.num_envs = -12345;
+    { int rc_ = d2d_create(&cfg, &h); if (rc_ != D2D_ERR_NO_MEMORY || d2d_last_error()[0] == 0) { fprintf(stderr, "bad_alloc came back as %d\n", rc_); ++failures; } }
+    cfg = good; cfg.num_envs = -12346;
+    { int rc_ = d2d_create(&cfg, &h); if (rc_ != D2D_ERR_STATE || strstr(d2d_last_error(), "test hook") == NULL) { fprintf(stderr, "runtime_error came back as %d (%s)\n", rc_, d2d_last_error()); ++failures; } }
+    cfg = good; cfg.num_envs = -12347;
+    { int rc_ = d2d_create(&cfg, &h); if (rc_ != D2D_ERR_STATE || d2d_last_error()[0] == 0) { fprintf(stderr, "a foreign exception came back as %d\n", rc_); ++failures; } }
+#endif
     if (h != NULL) { fprintf(stderr, "a failed d2d_create must leave *out NULL\n"); ++failures; }
 
     int rc = d2d_create(&good, &h);
@@ -132,8 +140,14 @@ int main(void) {
     EXPECT_ERR(d2d_allgather(h, fone, fone, 4, NULL));               /* no communicator */
     EXPECT_ERR(d2d_comm_init(h, 2, 5, id));
     EXPECT_ERR(d2d_profile_read(h, 7, &rate, &launches));
-    EXPECT_ERR(d2d_probe_write_bandwidth(h, 1024, 1, &rate));
-    EXPECT_ERR(d2d_probe_write_staged(h, NULL, (size_t)1 << 26, 500, 0, 1, &rate));
+    EXPECT_ERR(d2d_set_path_loss_link_table(h, one, 2, 0));          /* before d2d_set_links */
+    EXPECT_ERR(d2d_set_tuning(h, 9 /* D2D_TUNE_STEP_ABLATE, d2d_hip_diag.h */, 1));   /* release build: diagnostic keys refused */
+    EXPECT_ERR(d2d_set_tuning(h, D2D_TUNE_STEP_WALK, 1));           /* the flattened walk: diagnostic builds only */
+    {   /* a per-env table of 2^20 envs x 7 x 7 doubles is never read past the handle's own 3 x 7 x 7: sizes come from the handle */
+        const int32_t tx[2] = {1, 2}, rx[2] = {0, 0}, ty[2] = {1, 1};
+        if (d2d_set_links(h, 2, tx, rx, ty) != D2D_OK) { fprintf(stderr, "d2d_set_links failed: %s\n", d2d_last_error()); ++failures; }
+        EXPECT_ERR(d2d_set_path_loss_link_table(h, one, 3, 0));      /* not the length of the link list */
+    }
     if (d2d_destroy(h) != D2D_OK) { fprintf(stderr, "d2d_destroy failed\n"); ++failures; }
     printf("{\"gpu\": 1, \"failures\": %d}\n", failures);
     return failures ? 1 : 0;

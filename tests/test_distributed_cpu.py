@@ -142,7 +142,7 @@ def _modes_worker(rank, world, port, out_dir):
     valid = g.flush()
     block, _ = g.wait()
     want = torch.stack([torch.cat([local(r, s)[0][:, 0] for r in range(world)]) for s in (4, 5)])
-    if valid != 2 or g.reward_step != 4 or not torch.equal(block[:2], want) or g.flush() != 0:
+    if valid != 2 or g.reward_step != 4 or tuple(block.shape)[0] != 2 or g.reward_valid != 2 or not torch.equal(block, want) or g.flush() != 0:
         errors.append('flush of a partial reward ring')
     for step in range(6, 10):                            # the next block starts clean after a flush
         g.launch(*local(rank, step))

@@ -2,8 +2,12 @@
 per-env reward layout (D2D_REWARD_PER_ENV), the link-position rows (D2D_BUF_LINK_POS), the obs-less learner configuration
 (SignalPlanesObsFunction + StepGatherer(mode='planes')), zero distance under the power-law path loss, guard words around
 every bound buffer, the staged write probe."""
+from pathlib import Path
+
 import numpy as np
 import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
 
 from golden_util import rel_err
 from oracle import d2d_oracle as orc
@@ -306,21 +310,20 @@ def test_guard_words_around_every_bound_buffer_survive(native, case):
 
 
 def test_staged_write_probe(native):
-    """d2d_probe_write_staged: the fill family with an LDS stage + barrier and / or a per-wave sleep stagger in front of the
-    stores - runs, writes what it says, refuses nonsense."""
-    from gym_d2d_amd.simulator import Simulator
-    sim = Simulator(dict(num_rbs=2, num_cues=2, num_due_pairs=2, num_envs=1))
-    h = sim.handle
+    """libd2d_probe.so's staged forms: the fill family with an LDS stage + barrier and / or a per-wave sleep stagger in front of
+    the stores - runs, writes what it says, refuses nonsense."""
+    import sys
+    sys.path.insert(0, str(ROOT / 'tools'))
+    import write_probe
     for variant, stagger in ((0, 0), (32, 0), (64, 2), (96, 1), (32 + 1, 0), (128, 0), (256 + 32, 0), (384, 0), (512 + 1, 0)):
-        assert h.probe_write_staged(64 << 20, variant, stagger, iters=2) > 100.0
+        assert write_probe.write_staged(64 << 20, variant, stagger, iters=2) > 100.0
     import torch
     dst = torch.zeros(64 << 18, dtype=torch.float32, device='cuda')       # 64 MiB
-    assert h.probe_write_staged(64 << 20, 32, 0, iters=1, dst_ptr=dst.data_ptr()) > 100.0
-    with pytest.raises(native.NativeError):
-        h.probe_write_staged(1 << 20, 0)
-    with pytest.raises(native.NativeError):
-        h.probe_write_staged(64 << 20, 640)
-    sim.handle.close()
+    assert write_probe.write_staged(64 << 20, 32, 0, iters=1, dst_ptr=dst.data_ptr()) > 100.0
+    with pytest.raises(ValueError):
+        write_probe.write_staged(1 << 20, 0)
+    with pytest.raises(ValueError):
+        write_probe.write_staged(64 << 20, 640)
 
 
 def test_lists_are_not_taken_automatically_where_they_cannot_help(native):
@@ -406,17 +409,22 @@ def test_rollout_kernel_serves_the_obs_less_mode(native):
 
 
 def test_obs_block_placement_trials(native):
-    """VecD2DEnv(placement_trials=K): the first reset() times K candidate obs blocks and keeps the fastest; the observation
-    it returns, and every later step, are bit-identical to an env that took the first block."""
+    """VecD2DEnv(placement_trials=K), OPT-IN (default 0: a plain constructor allocates nothing beyond its own buffers): the first
+    reset() times K candidate obs blocks, keeps the fastest, never holds more than placement_budget_bytes of candidates +
+    paddings, leaves the caller's caching allocator alone; the observation it returns, and every later step, are
+    bit-identical to an env that took the first block."""
     import torch
     from gym_d2d_amd.envs import VecD2DEnv
     cfg = {'num_rbs': 25, 'num_cues': 25, 'num_due_pairs': 25}
-    plain = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic', placement_trials=0)
+    plain = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic')
+    assert plain._placement_trials == 0                                        # the default
+    mine = torch.empty(64 << 20, dtype=torch.uint8, device='cuda'); del mine   # a block of the CALLER's in torch's cache
+    cached = torch.cuda.memory_reserved()
     tuned = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic', placement_trials=3)
-    auto = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic')
     o0, o1 = plain.reset(seed=4), tuned.reset(seed=4)
-    assert plain.placement is None and auto._placement_trials == 24           # 15 MB obs block, fused step: inside 'auto'
+    assert plain.placement is None
     assert len(tuned.placement['us_per_step']) == 3 and 0 <= tuned.placement['chosen'] < 3 and tuned.placement['buffer'] == 'obs'
+    assert torch.cuda.memory_reserved() >= cached                              # no empty_cache() behind the caller's back
     assert torch.equal(o0, o1) and o1.data_ptr() == tuned._t['obs'].data_ptr()
     for k in range(3):
         act = torch.randint(0, 25 * 21, (256, 25), device=plain.device, dtype=torch.int32)
@@ -424,18 +432,20 @@ def test_obs_block_placement_trials(native):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     o0, o1 = plain.reset(), tuned.reset()                                      # trials run once per env
     assert torch.equal(o0, o1) and len(tuned.placement['us_per_step']) == 3
-    big = VecD2DEnv({'num_rbs': 64, 'num_cues': 100, 'num_due_pairs': 100}, num_envs=4)
-    assert big._placement_trials == 0                                          # two launches per step: not the fused small-N case
+    # the budget: a 15 MB obs block + paddings of 2 - 22 MB under a 40 MB cap leaves room for ONE more candidate at most
+    capped = VecD2DEnv(dict(cfg), num_envs=256, cue_actions='traffic', placement_trials=8, placement_budget_bytes=40 << 20)
+    capped.reset(seed=4)
+    assert len(capped.placement['us_per_step']) <= 2 and capped.placement['transient_bytes'] <= 40 << 20
     # the compact-obs step: the table is the block that is placed
     from gym_d2d_amd.envs.obs_fn import OwnLinkObsFunction
-    t0 = VecD2DEnv({'num_rbs': 64, 'num_cues': 128, 'num_due_pairs': 128, 'obs_fn': OwnLinkObsFunction}, num_envs=512, placement_trials=0)
+    t0 = VecD2DEnv({'num_rbs': 64, 'num_cues': 128, 'num_due_pairs': 128, 'obs_fn': OwnLinkObsFunction}, num_envs=512)
     t1 = VecD2DEnv({'num_rbs': 64, 'num_cues': 128, 'num_due_pairs': 128, 'obs_fn': OwnLinkObsFunction}, num_envs=512, placement_trials=4)
     a, b = t0.reset(seed=2), t1.reset(seed=2)
     assert t1.placement['buffer'] == 'table' and 1 <= len(t1.placement['us_per_step']) <= 4 and torch.equal(a, b)
     act = torch.randint(0, 64 * 21, (512, 256), device=t0.device, dtype=torch.int32)
     ra, rb_ = t0.step(act), t1.step(act)
     assert torch.equal(ra[0], rb_[0]) and torch.equal(ra[1], rb_[1]) and rb_[0].data_ptr() == t1._t['table'].data_ptr()
-    for e in (plain, tuned, auto, big, t0, t1):
+    for e in (plain, tuned, capped, t0, t1):
         e.close()
 
 

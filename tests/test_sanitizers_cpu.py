@@ -71,7 +71,9 @@ def test_c_oracle_under_address_and_undefined_sanitizers(tmp_path):
 
 def test_c_abi_argument_validation_under_host_sanitizers(tmp_path):
     """No GPU is needed (and none is used here): every call is refused before any HIP work, d2d_create itself fails with
-    D2D_ERR_HIP in this container.  What is checked is that the refusals are clean under ASan + UBSan."""
+    D2D_ERR_HIP in this container.  What is checked is that the refusals are clean under ASan + UBSan, and - with the
+    instrumented library built with -DD2D_TEST_HOOKS=1 - that a std::bad_alloc, a std::exception and a foreign exception
+    thrown inside an entry point come back as D2D_ERR_NO_MEMORY / D2D_ERR_STATE with a message (the exception barrier)."""
     from gym_d2d_amd import build as b
     hipcc = b._hipcc()
     clang = Path('/opt/rocm/lib/llvm/bin/clang')
@@ -82,7 +84,7 @@ def test_c_abi_argument_validation_under_host_sanitizers(tmp_path):
     san = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined']
     capi = tmp_path / 'd2d_capi_san.o'
     flags = [f for f in b.FLAGS if f != '-O3']
-    r = subprocess.run([hipcc, '-O1', '-g', *flags, *san, '-I', str(b.INCLUDE), '-c', str(b.CSRC / 'd2d_capi.hip'), '-o', str(capi)],
+    r = subprocess.run([hipcc, '-O1', '-g', *flags, *san, '-DD2D_TEST_HOOKS=1', '-I', str(b.INCLUDE), '-c', str(b.CSRC / 'd2d_capi.hip'), '-o', str(capi)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     lib = tmp_path / 'libd2d_hip.so'
@@ -91,7 +93,7 @@ def test_c_abi_argument_validation_under_host_sanitizers(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     exe = tmp_path / 'abi_validation'
-    r = subprocess.run([str(clang), '-std=c99', '-O1', '-g', '-Wall', '-Werror', *san, '-I', str(ROOT / 'include'),
+    r = subprocess.run([str(clang), '-std=c99', '-O1', '-g', '-Wall', '-Werror', *san, '-DD2D_TEST_HOOKS=1', '-I', str(ROOT / 'include'),
                         str(ROOT / 'tests' / 'c' / 'abi_validation.c'), '-L', str(tmp_path), '-ld2d_hip', f'-Wl,-rpath,{tmp_path}',
                         '-o', str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
