@@ -295,6 +295,9 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='stress', choices=sorted(WORKLOADS))
     ap.add_argument('--obs', default='linear', choices=['linear', 'table', 'none'])
+    ap.add_argument('--obs-dtype', default='float32', choices=['float32', 'float64'],
+                    help="--obs linear: element type of the [B, N, 6N] block; float64 is the reference's own (obs_fn.py:47,51), written by the "
+                         'expansion kernel itself (48 N bytes per agent-step)')
     ap.add_argument('--envs', type=int, default=0, help='override envs per GPU')
     ap.add_argument('--cue-actions', default='', choices=['', 'agent', 'traffic'],
                     help="who drives the CUE links (default: the workload's own choice)")
@@ -336,21 +339,23 @@ GROUP = 20          # launches per HIP-event pair when a step is a single kernel
 CORE_BYTES = 40.0   # action 4 + positions 16 + outputs 16 + reward 4, per agent-step
 
 
-def algorithmic_bytes(n, obs, reward_per_env=False):
-    """Per agent-step: the 40 core bytes + 24 N for the materialised LinearObs (+ the 24 the expansion
-    reads) or + 24 for the compact table.  reward_per_env: SystemCapacity's scalar once per env (4 / N bytes per link)
-    instead of the 4-byte copy every agent gets."""
+def algorithmic_bytes(n, obs, reward_per_env=False, export=False, f64=False):
+    """Per agent-step: the 40 core bytes + 24 N for the materialised LinearObs (48 N as float64; + the 24 the
+    expansion reads) or + 24 for the compact table.  reward_per_env: SystemCapacity's scalar once per env (4 / N bytes per link)
+    instead of the 4-byte copy every agent gets.  export: + 8 for the decoded (rb, pwr) planes behind info['rb'] /
+    info['tx_pwr_dbm'] when the timed configuration writes them (d2d_set_export_actions(1), the public default)."""
     core = CORE_BYTES - 4.0 + 4.0 / n if reward_per_env else CORE_BYTES
-    return core + (24.0 * n if obs == 'linear' else (24.0 if obs == 'table' else 0.0))
+    return core + (8.0 if export else 0.0) + ((48.0 if f64 else 24.0) * n if obs == 'linear' else (24.0 if obs == 'table' else 0.0))
 
 
 class Session:
     """One workload on this rank's GPU: the env, its pre-generated actions and the timing loops."""
 
     def __init__(self, torch, args, key, obs, dev, rank, local, steps, warmup, *, envs=0, cue_mode='', tune='', stub=False,
-                 export=True, action_pool=0):
+                 export=True, action_pool=0, placement_trials=0, f64=False):
         self.torch, self.args, self.key, self.obs, self.dev, self.rank, self.stub = torch, args, key, obs, dev, rank, stub
         self.export = export
+        self.f64 = bool(f64) and obs == 'linear'
         w = dict(WORKLOADS[key])
         if envs:
             w['envs'] = envs
@@ -375,9 +380,11 @@ class Session:
             if w.get('plugin'):
                 from gym_d2d_amd.path_loss import FreeSpacePathLoss
                 cfg['path_loss_model'] = FreeSpacePathLoss
+            if self.f64:
+                cfg['obs_dtype'] = 'float64'
             self.reward_per_env = bool(getattr(args, 'reward_per_env', False)) and obs != 'linear'
             self.env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b, cue_actions=self.cue_mode, export_actions=export,
-                                 reward_per_env=self.reward_per_env)
+                                 reward_per_env=self.reward_per_env, placement_trials=placement_trials)
             self.h = h = self.env.simulator.handle
             self.n_agents = self.env.num_agents
             tune_keys = {'rows': _native.TUNE_OBS_ROWS_PER_WG, 'nt': _native.TUNE_OBS_NONTEMPORAL,
@@ -451,6 +458,8 @@ class Session:
         dt = time.perf_counter() - t0
         step_ms, step_n = h.profile_read(0)
         obs_ms, obs_n = h.profile_read(1)
+        step_med = h.profile_median(0) if self.events_in_timed and not self.stub else 0.0
+        obs_med = h.profile_median(1) if self.events_in_timed and not self.stub else 0.0
         h.profile_enable(False)
         if not self.events_in_timed and not self.stub:
             stream = torch.cuda.current_stream(self.dev)          # VecD2DEnv runs the library's kernels on this stream
@@ -467,34 +476,40 @@ class Session:
             step_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in pairs)
             step_n = sum(c for _, _, c in pairs)
             obs_ms, obs_n = 0.0, 0
-        return {'dt': dt, 'step_ms': step_ms, 'step_n': step_n, 'obs_ms': obs_ms, 'obs_n': obs_n}
+            per_group = sorted(e0.elapsed_time(e1) / c for e0, e1, c in pairs)
+            step_med, obs_med = (per_group[len(per_group) // 2] if per_group else 0.0), 0.0
+        return {'dt': dt, 'step_ms': step_ms, 'step_n': step_n, 'obs_ms': obs_ms, 'obs_n': obs_n, 'step_median_ms': step_med, 'obs_median_ms': obs_med}
 
     def roofline(self, t):
-        """The dominant kernel's block: algorithmic bytes per launch / its average launch duration (HIP events)."""
+        """The dominant kernel's block: algorithmic bytes per launch / its average launch duration (HIP events); the median
+        launch beside the mean (per launch where every launch has its own event pair, per group of launches otherwise)."""
         b, n = self.b, self.n
         fused = self.obs == 'linear' and not self.events_in_timed   # small N: the expansion runs inside the step launch
         if fused:
             per_launch = b * n * (CORE_BYTES + 24.0 * n)
-            avg_ms = t['step_ms'] / max(t['step_n'], 1)
+            avg_ms, med_ms = t['step_ms'] / max(t['step_n'], 1), t.get('step_median_ms', 0.0)
             roof = {'kernel': 'step_kernel (LinearObs expansion fused)'}
         elif self.obs == 'linear' and t['obs_n']:
-            # dominant kernel: obs expansion.  Algorithmic bytes per launch = B*N*(24N written + 24 read of T)
-            per_launch = b * n * (24.0 * n + 24.0)
-            avg_ms = t['obs_ms'] / t['obs_n']
-            roof = {'kernel': 'obs_expand_flat_kernel'}
+            # dominant kernel: obs expansion.  Algorithmic bytes per launch = B*N*(24N written (48N as float64) + 24 read of T)
+            per_launch = b * n * ((48.0 if self.f64 else 24.0) * n + 24.0)
+            avg_ms, med_ms = t['obs_ms'] / t['obs_n'], t.get('obs_median_ms', 0.0)
+            roof = {'kernel': 'obs_expand_flat_f64_kernel' if self.f64 else 'obs_expand_flat_kernel'}
         else:
-            per_launch = b * n * algorithmic_bytes(n, self.obs, getattr(self, 'reward_per_env', False))
-            avg_ms = t['step_ms'] / max(t['step_n'], 1)
-            roof = {'kernel': 'step_kernel'}
+            # what the TIMED configuration moves: the decoded (rb, pwr) planes count when it writes them
+            per_launch = b * n * algorithmic_bytes(n, self.obs, getattr(self, 'reward_per_env', False), self.current_export())
+            avg_ms, med_ms = t['step_ms'] / max(t['step_n'], 1), t.get('step_median_ms', 0.0)
+            roof = {'kernel': 'rollout_kernel / step_kernel'}
         ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roof.update({'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                     'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': per_launch, 'traffic': None,
+                     'avg_launch_ms': avg_ms, 'median_launch_ms': med_ms or None,
+                     'frac_at_median_launch': (per_launch / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if med_ms > 0 else None,
+                     'algorithmic_bytes_per_launch': per_launch, 'traffic': None,
                      'timing': ('HIP events around every launch on the library stream, inside the timed region' if self.events_in_timed
                                 else f'HIP events around groups of {GROUP} back-to-back launches (one kernel per step) on the '
                                      'library stream, in a second pass over the same steps; the timed region itself runs '
-                                     'without events')})
+                                     'without events; median = the median group')})
         if not self.stub:
-            attach_traffic(roof, self.key, self.obs + ('_per_env_reward' if getattr(self, 'reward_per_env', False) else ''),
+            attach_traffic(roof, self.key, self.obs + ('_f64' if self.f64 else '') + ('_per_env_reward' if getattr(self, 'reward_per_env', False) else ''),
                            bool(self.args.envs), self.current_export())
         return roof
 
@@ -539,10 +554,10 @@ class Session:
 
 def summarise(sess, t, steps, world=1):
     """A workload's entry under other_workloads / core_mode: throughput, ms per step and the roofline block."""
-    return {'workload': sess.w['name'], 'obs_mode': sess.obs, 'cue_actions': sess.cue_mode, 'steps': steps,
+    return {'workload': sess.w['name'], 'obs_mode': sess.obs + (' (float64)' if sess.f64 else ''), 'cue_actions': sess.cue_mode, 'steps': steps,
             'value': sess.b * sess.n * steps * world / t['dt'], 'unit': 'agent-steps/s', 'ms_per_step': t['dt'] / steps * 1e3,
-            'algorithmic_bytes_per_agent_step': algorithmic_bytes(sess.n, sess.obs) if not (sess.obs == 'linear' and sess.n > 128)
-            else 40.0 + 24.0 * sess.n,
+            'algorithmic_bytes_per_agent_step': algorithmic_bytes(sess.n, sess.obs, getattr(sess, 'reward_per_env', False),
+                                                                  sess.current_export() and sess.obs != 'linear', sess.f64),
             'roofline': sess.roofline(t)}
 
 
@@ -614,7 +629,7 @@ def worker(args):
             torch.cuda.synchronize(dev)
 
     sess = Session(torch, args, args.workload, args.obs, dev, rank, local, args.steps, args.warmup, envs=args.envs,
-                   cue_mode=args.cue_actions, tune=args.tune, stub=stub, export=not args.no_export,
+                   cue_mode=args.cue_actions, tune=args.tune, stub=stub, export=not args.no_export, f64=args.obs_dtype == 'float64',
                    action_pool=128 if args.steps + args.warmup > 128 else 0)      # long runs: 128 action tensors (1 GB at 4096 x 512) round-robin
     b, n = sess.b, sess.n
 
@@ -665,7 +680,7 @@ def worker(args):
     # The decoded (rb, pwr) planes behind info['rb'] / info['tx_pwr_dbm'] are a rollout's own actions again: the entry is
     # measured without them (d2d_set_export_actions(0), 64 algorithmic bytes per link) and, beside it, with them.
     core = None
-    if not stub and sess.obs == 'linear' and n > 128 and (world == 1 or not args.no_gather):
+    if not stub and sess.obs == 'linear' and not sess.f64 and n > 128 and (world == 1 or not args.no_gather):
         core = core_mode(torch, sess, dev, args, fence, use_dist, world, make_gatherer)
 
     dt = t['dt']
@@ -697,7 +712,7 @@ def worker(args):
 
     extras = {}
     if rank == 0 and world == 1 and not stub and not args.no_extras and args.workload == 'stress' and args.obs == 'linear' \
-            and not args.envs and not args.tune:
+            and not args.envs and not args.tune and not sess.f64:
         sess.close()
         extras = n1_extras(torch, args, dev, local, fence)
 
@@ -719,10 +734,12 @@ def worker(args):
             'metric': 'env agent-steps/sec (batch x agents)', 'value': value, 'unit': 'agent-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'obs_dtype': 'float64' if sess.f64 else 'float32',
             'config': cfg,
             'roofline': roof,
             'kernels': {'step_kernel_ms': t['step_ms'] / max(t['step_n'], 1), 'obs_expand_kernel_ms': (t['obs_ms'] / t['obs_n']) if t['obs_n'] else None},
-            'algorithmic_bytes_per_agent_step': algorithmic_bytes(n, sess.obs, getattr(sess, 'reward_per_env', False)),
+            'algorithmic_bytes_per_agent_step': algorithmic_bytes(n, sess.obs, getattr(sess, 'reward_per_env', False),
+                                                                  sess.export and sess.obs != 'linear', sess.f64),
             'status_flags': flags,
             'target_agent_steps_per_s': 1e7,
         }
@@ -740,6 +757,26 @@ def worker(args):
         for k in ('other_workloads', 'vec_env_step_ms', 'box_write_ceiling'):
             if k in extras:
                 out[k] = extras[k]
+        # the secondary figures as FLAT scalars (a parser that keeps only top-level scalars still carries them)
+        def _frac(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d.get('frac') if isinstance(d, dict) else None
+        ow = extras.get('other_workloads', {})
+        flat = {'frac_config2': _frac(ow, 'default', 'roofline'), 'us_per_step_config2': (ow.get('default') or {}).get('ms_per_step'),
+                'frac_config2_with_placement_trials': (ow.get('default') or {}).get('with_placement_trials_24', {}).get('frac'),
+                'frac_config4': _frac(ow, 'plugin', 'roofline'), 'frac_obs_float64': _frac(ow, 'stress_float64_obs', 'roofline'),
+                'frac_table_no_export': _frac(core or {}, 'roofline'), 'frac_table_with_export': _frac(core or {}, 'with_decoded_rb_pwr_export', 'roofline'),
+                'frac_obsless': _frac(core or {}, 'planes_only', 'roofline'),
+                'us_step_kernel_obsless': ((core or {}).get('planes_only', {}).get('roofline', {}) or {}).get('avg_launch_ms'),
+                'median_launch_ms': roof.get('median_launch_ms'), 'frac_at_median_launch': roof.get('frac_at_median_launch')}
+        if flat['us_per_step_config2'] is not None:
+            flat['us_per_step_config2'] *= 1e3
+        if flat['us_step_kernel_obsless'] is not None:
+            flat['us_step_kernel_obsless'] *= 1e3
+        if single_ms is not None:
+            flat['single_env_step_ms_default'] = single_ms.get('25 CUE + 25 DUE pairs, 25 RB (reference default env)')
+        out.update({k: v for k, v in flat.items() if v is not None})
         if cpu is not None:
             out['cpu_baseline'] = cpu
         elif world > 1:
@@ -835,22 +872,35 @@ def n1_extras(torch, args, dev, local, fence):
     the device-side reset, each with its own roofline block; the public VecD2DEnv.step against the bare handle loop; the
     box's write ceiling."""
     out = {'other_workloads': {}, 'vec_env_step_ms': {}}
+    sys.path.insert(0, str(ROOT / 'tools'))
+    import write_probe                                    # libd2d_probe.so: measurement equipment, not in the product library
     # BASELINE.json configs[1]: 1024 x 50, traffic-model CUEs, LinearObs fused into the step launch.  2000 + 2000 steps (60 ms):
     # behind an idle stretch (closing one session and building the next is host work) the chip needs about 1000 of these
     # 14 us steps (15 ms) to come back to its busy clocks and runs 5 - 10 % slower until then (tools/probes/clock_state.py,
     # profiles/r4_clock_state_default.jsonl) - a 220-step run measured the ramp, not the kernel
     s = Session(torch, args, 'default', 'linear', dev, 0, local, 2000, 2000, action_pool=256)
-    out['other_workloads']['default'] = summarise(s, s.timed(fence), 2000)
-    # where a 61 MB obs block lands decides its speed class (13.2 / 13.9 / 15.1 us per step, profiles/r4_obs_block_placement_candidates.jsonl):
-    # VecD2DEnv timed 6 candidate blocks at its first reset and kept the fastest - what it saw is part of the record
-    out['other_workloads']['default']['obs_block_placement_trials'] = getattr(s.env, 'placement', None)
+    out['other_workloads']['default'] = summarise(s, s.timed(fence), 2000)          # a plain VecD2DEnv(cfg, 1024): no placement trials
     try:                                                  # what a pure fill of about the same size reaches on this box (61 MB of obs per step)
-        small, _ = s.h.probe_write_variants(64 << 20, 20)
+        small, _ = write_probe.write_variants(64 << 20, 20, local)
         out['other_workloads']['default']['roofline']['box_ceiling_GBs_64MiB_bursts'] = small
     except Exception as exc:                              # pragma: no cover
         out['other_workloads']['default']['roofline']['box_ceiling_error'] = repr(exc)
     out['vec_env_step_ms']['default (config 2), LinearObs'] = s.vec_env_step_ms()
     s.close()
+    # ... and beside it, never as the entry's own figure: the same env built with the OPT-IN placement trials (where a 61 MB obs
+    # block lands decides its speed class - 13.2 / 13.9 / 15.1 us per step, profiles/r4_obs_block_placement_candidates.jsonl;
+    # VecD2DEnv(placement_trials=24) times candidate blocks at its first reset and keeps the fastest)
+    try:
+        s = Session(torch, args, 'default', 'linear', dev, 0, local, 2000, 2000, action_pool=256, placement_trials=24)
+        try:
+            e = summarise(s, s.timed(fence), 2000)
+            out['other_workloads']['default']['with_placement_trials_24'] = {
+                'value': e['value'], 'ms_per_step': e['ms_per_step'], 'frac': e['roofline']['frac'], 'avg_launch_ms': e['roofline']['avg_launch_ms'],
+                'trials': getattr(s.env, 'placement', None)}
+        finally:
+            s.close()
+    except Exception as exc:                              # pragma: no cover
+        out['other_workloads']['default']['with_placement_trials_24'] = {'error': repr(exc)}
     # BASELINE.json configs[3]: FreeSpacePathLoss + a custom ObsFunction through the plugin ABI, 4096 x 512
     s = Session(torch, args, 'plugin', 'table', dev, 0, local, 1000, 1000, action_pool=64)      # 58 ms: as above
     out['other_workloads']['plugin'] = summarise(s, s.timed(fence), 1000)
@@ -861,9 +911,20 @@ def n1_extras(torch, args, dev, local, fence):
     e = summarise(s, s.timed(fence, None, True), 30)
     e['positions'] = 'redrawn on the device every 10 steps (reset_kernel inside the timed region), 3 episodes'
     out['other_workloads']['stress_with_reset'] = e
+    s.close()
+    # the reference's own observation dtype (obs_fn.py:47,51: float64 arrays), written as float64 by the expansion kernel itself:
+    # 48 N bytes per agent-step, a 51.5 GB block
+    try:
+        s = Session(torch, args, 'stress', 'linear', dev, 0, local, 30, 5, f64=True)
+        try:
+            out['other_workloads']['stress_float64_obs'] = summarise(s, s.timed(fence), 30)
+        finally:
+            s.close()
+    except Exception as exc:                              # pragma: no cover
+        out['other_workloads']['stress_float64_obs'] = {'error': repr(exc)}
     # the write ceiling of THIS box: pure fill kernels in a family of store geometries that contains the obs kernel's own
     try:
-        best, rates = s.h.probe_write_variants(8 << 30, 5)
+        best, rates = write_probe.write_variants(8 << 30, 5, local)
         blocks, rows = (768, 1024, 512, 256), (2, 4, 8, 32)
         k = max(range(len(rates)), key=lambda v: rates[v])
         name = 'hipMemsetAsync' if k == 32 else f'{blocks[k & 3]} threads x {rows[(k >> 2) & 3]} rows per workgroup, ' + ('plain' if k & 16 else 'nontemporal') + ' stores'
@@ -875,20 +936,19 @@ def n1_extras(torch, args, dev, local, fence):
                                ('1024 threads x 2 rows, LDS stage + barrier, nt stores', 1 + 32),
                                ('768 threads x 2 rows (the obs kernel geometry), LDS stage + barrier, sc1 nt stores', 0 + 32 + 512),
                                ('768 threads x 2 rows (the obs kernel geometry), LDS stage + barrier, nt stores', 0 + 32)):
-            staged[label] = max(s.h.probe_write_staged(8 << 30, variant, 0, iters=5) for _ in range(2))
+            staged[label] = max(write_probe.write_staged(8 << 30, variant, 0, iters=5, device=local) for _ in range(2))
         kb = max(staged, key=staged.get)
         if staged[kb] > best:
             best, name = staged[kb], kb
         out['box_write_ceiling'] = {'GBps': best, 'best_variant': name, 'obs_kernel_geometry_GBps': rates[0], 'hipMemsetAsync_GBps': rates[32],
                                     'best_plain_fill_GBps': max(rates[:32]), 'staged_forms_GBps': staged,
-                                    'what': 'd2d_probe_write_variants: 8 GiB written 5 times by each of 32 pure fill kernels (block 768 / 1024 / 512 / 256 '
+                                    'what': 'libd2d_probe.so (include/d2d_hip_diag.h), d2d_probe_write_variants: 8 GiB written 5 times by each of 32 pure fill kernels (block 768 / 1024 / 512 / 256 '
                                             'threads x 2 / 4 / 8 / 32 rows per workgroup x nontemporal / plain 16-byte stores, XCD-grouped dispatch '
                                             'order; the first is the obs kernel\'s own geometry), by hipMemsetAsync, and by the staged forms of '
                                             'd2d_probe_write_staged (a table row through LDS behind a barrier before the stores; sc1 / sc0 sc1 scope bits '
                                             'with nt); GBps = the best of them'}
     except Exception as exc:                              # pragma: no cover - a probe failure must not lose the line
         out['box_write_ceiling'] = {'error': repr(exc)}
-    s.close()
     return out
 
 
@@ -912,8 +972,8 @@ def attach_traffic(roof, workload, obs, custom_envs, export=True):
             continue            # collected with / without the decoded (rb, pwr) planes: 8 bytes per link apart
         for kname, d in rec.get('kernels', {}).items():
             tag = roof['kernel'].split(' ')[0]
-            tag = 'obs_expand' if tag.startswith('obs_expand') else tag      # obs_expand_flat_kernel / obs_expand_kernel / obs_expand_f64_kernel
-            if tag in kname and 'hbm_bytes_per_launch' in d:
+            tags = ('obs_expand',) if tag.startswith('obs_expand') else (('rollout_kernel', 'step_kernel') if tag == 'rollout_kernel' else (tag,))
+            if any(t in kname for t in tags) and 'hbm_bytes_per_launch' in d:
                 if rec.get('source_digest') == digest:
                     roof['traffic'] = d['hbm_bytes_per_launch']
                     roof['traffic_source'] = (f'QUOTED, not measured in this run: profiles/{path.name} (WRITE_SIZE + 2*FETCH_SIZE, '

@@ -108,6 +108,7 @@ SIGNATURES = {
     'd2d_profile_enable': (C.c_int, [_P, _I]),
     'd2d_profile_read': (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'd2d_profile_reset': (C.c_int, [_P]),
+    'd2d_profile_median': (C.c_int, [_P, _I, C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -381,6 +382,12 @@ class Handle:
         ms, n = C.c_double(), C.c_int64()
         _check(self._lib.d2d_profile_read(self._h, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_median(self, kernel: int) -> float:
+        """Median launch duration (ms) of kernel 0 (step) / 1 (LinearObs expansion) since the last profile_reset()."""
+        ms = C.c_double()
+        _check(self._lib.d2d_profile_median(self._h, kernel, C.byref(ms)))
+        return ms.value
 
     def profile_reset(self) -> None:
         _check(self._lib.d2d_profile_reset(self._h))

@@ -128,6 +128,7 @@ struct d2d_handle {
     size_t events_used = 0;
     double acc_ms[2] = {0, 0};
     int64_t launches[2] = {0, 0};
+    std::vector<float> samples[2];                   // per-launch durations since the last reset (d2d_profile_median), at most 65536 each
 };
 
 namespace {
@@ -323,6 +324,7 @@ int drain_events(d2d_handle* h) {
         HIP_TRY(hipEventElapsedTime(&ms, h->events[k].start, h->events[k].stop));
         h->acc_ms[h->events[k].kernel] += ms;
         h->launches[h->events[k].kernel] += 1;
+        if (h->samples[h->events[k].kernel].size() < 65536) h->samples[h->events[k].kernel].push_back(ms);
     }
     h->events_used = 0;
     return D2D_OK;
@@ -337,10 +339,29 @@ struct OutPtrs {
 };
 
 // LinearObs expansion launch geometry for a [B, N, 6] table (shared by the step path and d2d_expand_table).
-void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float* obs, d2d::ObsArgs* out) {
+void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float* obs, int out_f64, d2d::ObsArgs* out) {
     d2d::ObsArgs o;
     std::memset(&o, 0, sizeof(o));
     o.B = B; o.N = N;
+    o.out_f64 = out_f64;
+    if (out_f64 && h->tune_variant != 3) {
+        // float64 block (d2d_set_obs_dtype): flat slabs of double2 pieces - one aligned float2 of T each, 3N per row, any N
+        o.vec = 2;
+        o.q_per_row = (unsigned)(3 * N);
+        o.q_magic = ((1ull << 40) + o.q_per_row - 1) / o.q_per_row;
+        o.block = h->tune_block > 0 ? h->tune_block : 1024;
+        int passes = h->tune_rows > 0 ? h->tune_rows : 2;
+        if (passes > 4) passes = 4;
+        o.rows_per_wg = passes;
+        const unsigned total = (unsigned)N * o.q_per_row, slab = (unsigned)passes * (unsigned)o.block;
+        o.chunks = (int)((total + slab - 1) / slab);
+        o.xcd_remap = (h->tune_xcd > 0 && B % 8 == 0) ? 1 : 0;
+        o.nontemporal = h->tune_nt;
+        o.variant = 2;
+        o.table = table; o.obs = obs;
+        *out = o;
+        return;
+    }
     o.vec = (6 * N) % 4 == 0 ? 4 : 2;
     o.q_per_row = (unsigned)(6 * N / o.vec);
     o.q_magic = ((1ull << 40) + o.q_per_row - 1) / o.q_per_row;
@@ -352,7 +373,7 @@ void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float*
     // is the one where every thread issues exactly TWO 16-B stores (6.96 TB/s vs 5.9 for 96-KiB slabs and 5.6 for 786-KiB slabs):
     // small slabs dispatched in order keep the chip-wide write front nearly sequential in address, and a workgroup never
     // outlives its neighbours.  D2D_TUNE_OBS_VARIANT = 3 keeps the row-aligned kernel (A/B, and 8-byte rows when 6N % 4 != 0).
-    const bool flat = o.vec == 4 && (h->tune_variant == 0 || h->tune_variant == 2) && !h->obs_f64;
+    const bool flat = o.vec == 4 && (h->tune_variant == 0 || h->tune_variant == 2) && !out_f64;
     int block = h->tune_block;
     if (block <= 0) {
         block = flat ? 1024 : (int)((o.q_per_row + 63) / 64) * 64;
@@ -380,7 +401,6 @@ void make_obs_args(const d2d_handle* h, int B, int N, const float* table, float*
     // float64 block's float32 consumers) the row-aligned default runs on the row-aligned geometry computed above
     o.variant = flat ? 2 : (h->tune_variant == 2 ? 0 : h->tune_variant);
     o.stagger = h->tune_stagger;
-    o.out_f64 = 0;
     o.table = table;
     o.obs = obs;
     *out = o;
@@ -422,10 +442,16 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // than four links per RB on average a ninth link on some RB is the rule, the list build is wasted and the workgroup
     // sweeps all pairs anyway (N > 8 R: by pigeonhole), so those shapes go straight to the sweep
     const bool lists_can_help = (long long)N <= 4ll * h->cfg.num_rbs;
-    // ... and in the obs-less mode (D2D_OBS_NONE), where the step is paced by its instruction streams rather than its stores: the
-    // lists' fixed batches of clamped pair evaluations (no exec-mask loops) take the rollout kernel from 21.0 to 19.5 us at 4096 x 512,
-    // while in the table modes, which are memory bound, they cost 1 - 4 % (profiles/r4_hot_member_lists_ab.jsonl)
-    const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE);
+    // The rollout kernel (d2d_rollout.hip) serves: raw agent actions for every link, SystemCapacity, one env per workgroup (N a
+    // multiple of 64, no fused expansion), a power-law path loss.  Round 5: it is the faster one in every obs mode (same box,
+    // 4096 x 512, r4 HEAD -> rollout: obs-less 21.3 -> 19.3 us, compact table 27.7 -> 25.8, with the decoded planes 28.3 -> 27.3;
+    // profiles/r5_ab_rollout_kernel.jsonl), so wherever it applies the lists are the default.
+    const bool will_fuse = h->obs_mode == D2D_OBS_LINEAR && !h->obs_f64 && (h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128);
+    const bool rollout_cfg = action_mode == 0 && h->n_fixed == 0 && h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY && h->bucketing &&
+                             !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && h->tune_step_ablate == 0 &&
+                             h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
+                             N % 64 == 0 && N <= 2048;
+    const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE || rollout_cfg);
     s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (lists_pay ? 2 : 0);
 
     // ---- launch geometry.  tpe threads per env (one per link up to 1024), epw envs per workgroup: small envs share a
@@ -467,9 +493,27 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     if (lists && d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) { lists = 0; s.walk = 0; }
     s.lpt = lpt;
     d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, &s.lds);
+    // The rollout kernel (d2d_rollout.hip): raw agent actions for every link, SystemCapacity, one env per workgroup, a power-law
+    // path loss, member lists wanted - one link per thread, or two (N / 2 threads per env: every per-wave instruction paid once
+    // per 128 links) when N is a multiple of 128.  Its own LDS layout: no masks, 15 KB per env at 512 links on 256 RBs.
+    if (lists && s.walk == 2 && rollout_cfg && h->col_mode == 0) {
+        // one link per thread, or two (N / 2 threads per env: every per-wave instruction paid once per 128 links, half the waves to
+        // launch) - measured: two win in the obs-less mode (19.3 vs 19.9 us), one where the table is written (25.8 vs 26.3); two
+        // only with scalar records (per-lane records for two links push the kernel past 64 VGPRs)
+        int rl = h->tune_step_lpt > 0 ? h->tune_step_lpt : (N % 128 == 0 && s.rec_uniform && h->obs_mode == D2D_OBS_NONE ? 2 : 1);
+        if ((rl == 2 && N % 128 != 0) || N / rl > 1024) rl = N <= 1024 ? 1 : 2;
+        if (N % (64 * rl) == 0 && N / rl <= 1024) {
+            d2d::StepLds rlds;
+            d2d::rollout_lds_layout(N, s.R, (int)h->mode, &rlds);
+            if (rlds.env_bytes <= 64 * 1024) {
+                s.rollout = 1; s.lds = rlds;
+                lpt = rl; tpe = N / rl; W = 0; s.lpt = lpt;
+            }
+        }
+    }
     const size_t env_lds = s.lds.env_bytes;
     if (env_lds > 160 * 1024) return fail(D2D_ERR_UNSUPPORTED, "links per env exceed the LDS staging capacity");
-    int epw = h->tune_step_epw;
+    int epw = s.rollout ? 1 : h->tune_step_epw;
     if (epw <= 0) epw = tpe >= 256 ? 1 : 256 / tpe;
     if (epw > h->B) epw = h->B;
     while (epw > 1 && ((size_t)epw * env_lds > 64 * 1024 || epw * tpe > 1024)) --epw;
@@ -570,8 +614,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
 
     if (h->obs_mode == D2D_OBS_LINEAR && !fuse) {
         d2d::ObsArgs o;
-        make_obs_args(h, h->B, N, s.table, s.obs, &o);
-        o.out_f64 = redirect ? 0 : h->obs_f64;                          // d2d_step_host's packed block is float32
+        make_obs_args(h, h->B, N, s.table, s.obs, redirect ? 0 : h->obs_f64, &o);      // d2d_step_host's packed block is float32
         rc = record_start(h, 1, &ep);
         if (rc) return rc;
         HIP_TRY(d2d::launch_obs_expand(o, h->stream));
@@ -1194,7 +1237,7 @@ int d2d_expand_table(d2d_handle* h, const float* table_dev, int32_t n_envs, int3
     if (n_envs < 1 || n_links < 1 || n_links > D2D_MAX_LINKS) return fail(D2D_ERR_INVALID, "n_envs >= 1 and 1 <= n_links <= D2D_MAX_LINKS");
     USE_DEVICE(h);
     d2d::ObsArgs o;
-    make_obs_args(h, n_envs, n_links, table_dev, obs_dev, &o);
+    make_obs_args(h, n_envs, n_links, table_dev, obs_dev, 0, &o);
     EventPair* ep = nullptr;
     int rc = record_start(h, 1, &ep);
     if (rc) return rc;
@@ -1344,6 +1387,19 @@ int d2d_profile_reset(d2d_handle* h) try {
     int rc = drain_events(h);
     if (rc) return rc;
     h->acc_ms[0] = h->acc_ms[1] = 0; h->launches[0] = h->launches[1] = 0;
+    h->samples[0].clear(); h->samples[1].clear();
+    return D2D_OK;
+} D2D_CATCH
+
+int d2d_profile_median(d2d_handle* h, int32_t kernel, double* median_ms) try {
+    if (!h || !median_ms || kernel < 0 || kernel > 1) return fail(D2D_ERR_INVALID, "bad argument");
+    USE_DEVICE(h);
+    int rc = drain_events(h);
+    if (rc) return rc;
+    std::vector<float> v = h->samples[kernel];
+    if (v.empty()) { *median_ms = 0.0; return D2D_OK; }
+    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+    *median_ms = v[v.size() / 2];
     return D2D_OK;
 } D2D_CATCH
 

@@ -29,7 +29,7 @@ enum PlMode : int {
 
 // Byte offsets of one env's LDS arrays (step_lds_layout): only what the configuration reads back is allocated.
 struct StepLds {
-    unsigned aux, rx, sinr, sh, expo, tflat, mask, lists, env_bytes;
+    unsigned aux, rx, sinr, sh, expo, tflat, mask, lists, pool, env_bytes;
 };
 
 struct StepArgs {
@@ -37,6 +37,7 @@ struct StepArgs {
     int B, N, R, D;
     int mask_words;          // ceil(N/32): u32 words per RB membership mask (0 -> all-pairs path)
     int lpt;                 // links per thread held in registers: 1, 2, or 0 = strided
+    int rollout;             // the rollout kernel (d2d_rollout.hip) serves this launch; lds = rollout_lds_layout
     StepLds lds;             // LDS layout of one env
     int action_mode;         // 0: raw int actions (a // P, a % P)   1: explicit rb / pwr
     int act_stride;          // columns of the action array(s): N - n_fixed in mode 0, N in mode 1
@@ -116,7 +117,8 @@ struct ObsArgs {
 };
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
-hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, size_t lds, hipStream_t stream);
+hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, hipStream_t stream);
+void rollout_lds_layout(int N, int R, int mode, StepLds* out);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists);
 void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out);

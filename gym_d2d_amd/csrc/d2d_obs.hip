@@ -198,6 +198,51 @@ __global__ __launch_bounds__(1024) void obs_expand_f64_kernel(const ObsArgs a) {
     }
 }
 
+// Flat slabs in float64 (round 5): the shape of obs_expand_flat_kernel for the reference's observation dtype.  A 16-byte piece is
+// one double2 = ONE aligned float2 of T, so the env's [N][6N] block is a flat array of N * 3N pieces; a 1024-thread workgroup
+// writes `passes` x 1024 consecutive pieces (16 KB per pass) whatever the row length, every lane's (row, column) found once per
+// piece by multiply-shift, all LDS reads issued ahead of the stores.  (The row-aligned kernel above walked a row with a strided
+// loop and a three-way source select per element: 6.6 TB/s where this shape's float32 twin does 7.1 - 7.2, profiles/r4_obs_float64.jsonl.)
+template <int NT>
+__global__ __launch_bounds__(1024) void obs_expand_flat_f64_kernel(const ObsArgs a) {
+    extern __shared__ __align__(16) float t_flat[];          // [6N]
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const unsigned N = a.N, tid = threadIdx.x, T = blockDim.x;
+    unsigned env, chunk;
+    if (a.xcd_remap) {
+        const unsigned bid = blockIdx.x, lane8 = bid & 7u, rest = bid >> 3;
+        chunk = rest % a.chunks; env = (rest / a.chunks) * 8u + lane8;
+    } else {
+        env = blockIdx.x / a.chunks; chunk = blockIdx.x % a.chunks;
+    }
+    const unsigned row_floats = 6u * N, q_per_row = a.q_per_row, total = N * q_per_row;      // q_per_row = 3N double2 per row
+    {
+        const f32x2* src = reinterpret_cast<const f32x2*>(a.table + (size_t)env * row_floats);
+        f32x2* dst = reinterpret_cast<f32x2*>(t_flat);
+        for (unsigned k = tid; k < row_floats / 2; k += T) dst[k] = src[k];
+    }
+    __syncthreads();
+    const f32x2* t2 = reinterpret_cast<const f32x2*>(t_flat);
+    f64x2* out = reinterpret_cast<f64x2*>(reinterpret_cast<double*>(a.obs) + (size_t)env * N * row_floats);
+    const unsigned base = chunk * (unsigned)a.rows_per_wg * T;            // rows_per_wg = passes per workgroup here
+    f32x2 v[4];
+    unsigned idx[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        idx[p] = base + (unsigned)p * T + tid;
+        if (p < a.rows_per_wg && idx[p] < total) {
+            const unsigned i = (unsigned)(((unsigned long long)idx[p] * a.q_magic) >> 40), c = idx[p] - i * q_per_row;
+            v[p] = t2[src_col(2u * c, i) >> 1];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (p < a.rows_per_wg && idx[p] < total) {
+            const f64x2 d = {(double)v[p].x, (double)v[p].y};
+            if (NT) __builtin_nontemporal_store(d, out + idx[p]); else out[idx[p]] = d;
+        }
+}
+
 // Variant without LDS staging or barrier (float4 rows only): every thread fetches its two source float2 straight
 // from T in global memory (L1 / the XCD's L2 after the first touch) and stores.  Selected by D2D_TUNE_OBS_VARIANT=1;
 // kept for A/B measurement against the staged kernel (tools/tune_obs.py).
@@ -236,7 +281,10 @@ hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.N * 6 * sizeof(float);
     dim3 grid((unsigned)a.B * (unsigned)a.chunks), block(a.block > 0 ? a.block : 256);
     if (a.out_f64) {
-        if (a.nontemporal) hipLaunchKernelGGL(obs_expand_f64_kernel<true>, grid, block, lds, stream, a);
+        if (a.variant == 2 && a.rows_per_wg <= 4) {            // flat slabs (the default)
+            if (a.nontemporal) hipLaunchKernelGGL((obs_expand_flat_f64_kernel<1>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((obs_expand_flat_f64_kernel<0>), grid, block, lds, stream, a);
+        } else if (a.nontemporal) hipLaunchKernelGGL(obs_expand_f64_kernel<true>, grid, block, lds, stream, a);
         else hipLaunchKernelGGL(obs_expand_f64_kernel<false>, grid, block, lds, stream, a);
         return hipGetLastError();
     }

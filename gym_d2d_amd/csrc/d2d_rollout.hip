@@ -1,18 +1,20 @@
 // Rollout kernel for gfx950 (MI355X): the step of a learner's rollout - raw agent actions for every link, SystemCapacity
-// reward, one env per 512-thread (N-thread) workgroup, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE fast path.
+// reward, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
 //
 // Reference path (file:line under /root/reference/src/gym_d2d): the same as csrc/d2d_step.hip -
 //   D2DEnv._decode_action envs/d2d_env.py:93-101, Actions.get_actions_by_rb actions.py:27-31,
 //   Simulator._calculate_sinrs / _snrs / _rates / _network_capacity simulator.py:89-154,
 //   SystemCapacityRewardFunction envs/reward_fn.py:27-44, LinearObsFunction's base table envs/obs_fn.py:55-61.
 //
-// Why a kernel of its own (round 5): at 36 - 64 bytes per link the step is paced by its instruction streams, not by HBM
-// (profiles/r4_elasticity_step_kernel.json: +96 SALU per wave = +25 %, +64 VALU = +10 %).  The generic kernel's member-list
-// walk spent 70 of its 246 VALU per wave on taking the own entry out of the RB's list, sorting the rest and clamping the
-// indices, and ~40 of its 102 SALU on exec-mask bookkeeping around per-lane rarities.  This kernel
-//   * keeps every per-lane rarity (action beyond the multiply-high decode's range or beyond R * P, a ninth link on an RB)
-//     out of the instruction stream: such a lane raises ONE workgroup flag in pass 1 and the whole workgroup then takes the
-//     general path (exact decode, membership masks, nested walk - the generic kernel's code) behind one scalar branch;
+// Why a kernel of its own (round 5): at 36 - 64 bytes per link the step is paced by the instructions a CU can issue, of every
+// kind (profiles/r4_elasticity_step_kernel.json; about one wave-instruction per cycle and CU), not by HBM.  The generic
+// kernel's member-list walk spent 70 of its 246 VALU per wave on taking the own entry out of the RB's list, sorting the rest
+// and clamping the indices, and ~40 of its 102 SALU on exec-mask bookkeeping around per-lane rarities.  This kernel
+//   * keeps every per-lane rarity behind wave-uniform ballot branches that the common wave never enters: an action beyond the
+//     multiply-high decode's bound (refresh_tables keeps it below R * P, so inside it the quotient is exact AND a valid RB) is
+//     decoded by division; a link whose RB lies outside [0, R) enters no list and sweeps all pairs; the ninth and later links
+//     of an RB go to a per-env OVERFLOW POOL of (rb, link) pairs that only the members of such an RB ever scan - no
+//     membership masks, no workgroup-wide fallback, 15 KB of LDS per env instead of 37 KB;
 //   * stores the list entries as LDS BYTE OFFSETS of the members' tuples (u16, link * 16; empty = N * 16, the zero-power
 //     stand-in tuple), so an entry is an address: no clamp, no shift;
 //   * does NOT sort and does NOT take the own entry out: the interference sum starts at minus the own term and adds all
@@ -20,8 +22,19 @@
 //     smallest non-zero term of a lane are less than 2^25 apart, every partial sum of the at most nine values is exact,
 //     hence independent of the order and equal - bit for bit - to the ascending-order sum of the mask walk and the
 //     all-pairs sweep.  The two extremes are tracked with one v_max3 / v_min3 pair per two terms; a lane outside the
-//     window (1e-6 of lanes without, 5e-5 with the own term at BASELINE config 3 geometry) re-does its sum in sorted order.
+//     window (1e-6 of lanes without, 5e-5 with the own term at BASELINE config 3 geometry) re-does its sum in sorted order;
+//   * LPT = 2: a thread carries two links (t and t + N / 2), so every per-WAVE instruction - scalar loads, barriers, ballots,
+//     the wave reduction, the ticket - is paid once per 128 links instead of once per 64, and half as many waves are launched.
 // Same arithmetic as step_kernel everywhere else (tests/test_gpu_step_variants.py holds the two bit-identical).
+//
+// Worst case: an env whose actions pile more than eight links on one RB costs its members a scan of the pool (<= N entries);
+// a lane whose terms then fall outside the exactness window (25 bits at 9 - 15 members ... 18 at 2047) takes them in ascending
+// order by selection (up to 32 members) or by one all-pairs sweep - bounded by N pair evaluations per link, what the
+// reference's own loop does (simulator.py:95-101).  (A first version swept at an 18-bit window whatever the member count: a
+// few hundred lanes per launch at BASELINE config 3, each outliving the launch - 47 us median against a 16 us minimum.)  A workload that lives there
+// (N > 4 R on average) is not given this kernel (run_step), and D2D_TUNE_STEP_WALK = 0 keeps the mask walk for any other.
+#include <cstring>
+
 #include "d2d_step_device.h"
 
 namespace d2d {
@@ -29,55 +42,80 @@ namespace d2d {
 #define RO_SLOTS 8
 #define RO_ST(ptr, val) do { if (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 
-__device__ __forceinline__ float2 lds_f2(unsigned addr) { const f32x2 v = lds_get<f32x2>(addr); return make_float2(v.x, v.y); }
+// LDS of one env (byte offsets; StepLds): 0 sum (u64) ... 60 dump (u16) | 64 flags[4]: env flags, reward bits, ticket, pool count
+// | 80 link[N + 1] tuples | expo[N + 1] (power law) | slots[R + 1] (8 x u16) | cnt[R + 1] | pool[N] (rb, link)
+void rollout_lds_layout(int N, int R, int mode, StepLds* out) {
+    std::memset(out, 0, sizeof(*out));
+    unsigned off = LDS_HEAD_BYTES + ((unsigned)N + 1u) * 16u;
+    out->expo = off; if (mode == PL_POWER) off += ((unsigned)N + 1u) * 8u;
+    off = (off + 15u) & ~15u;
+    out->lists = off; off += ((unsigned)R + 1u) * 16u + (((unsigned)R + 1u + 3u) & ~3u) * 4u;
+    out->pool = off; off += (unsigned)N * 8u;
+    out->env_bytes = (off + 15u) & ~15u;
+}
 
-template <int MODE, int OPT>
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2 lds_f2(unsigned addr) { const f32x2 v = lds_get<f32x2>(addr); return make_float2(v.x, v.y); }
+__device__ __forceinline__ unsigned lds_atomic_inc(unsigned addr) {
+    return __hip_atomic_fetch_add((D2D_LDS(unsigned)*)(addr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // ds_add_rtn_u32
+}
+__device__ __forceinline__ void lds_atomic_or(unsigned addr, int bits) {
+    __hip_atomic_fetch_or((D2D_LDS(int)*)(addr), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int MODE, int OPT, int LPT>
 __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     constexpr bool SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0;
     constexpr bool POWLAW = MODE == PL_POWER;
     static_assert(MODE == PL_INV_SQUARE || MODE == PL_POWER, "the rollout kernel serves the power laws");
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int N = a.N, R = a.R, W = a.mask_words, TPE = a.tpe;
-    const int tid = threadIdx.x, i = tid, b = (int)blockIdx.x;
+    static_assert(LPT == 1 || LPT == 2, "one or two links per thread");
+    const int N = a.N, R = a.R, TPE = a.tpe;                     // N == LPT * TPE == LPT * blockDim.x
+    const int tid = threadIdx.x, b = (int)blockIdx.x;
     const unsigned row = (unsigned)b * (unsigned)N;              // element offsets fit 32 bits (run_step refuses B * N * 24 >= 2^32)
-    const Smem s = carve(smem_raw, a.lds, R, W);
     const bool cfg_export_actions = a.rb_out != nullptr;
     const unsigned EMPTY = (unsigned)N * 16u;                    // byte offset of the stand-in tuple link[N]
+    const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
+    const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u;
 
-    // ---- prologue: this link's loads, issued before any LDS work or barrier (their latency overlaps pass 0)
-    LinkRaw in;
-    if (SREC) {
-        // the records of this wave's 64 links are identical (StepArgs::rec_uniform): the whole record in one 64-byte scalar load
-        in.act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
-        in.act1 = 0;
-        const i32x16 g = scalar_load64(reinterpret_cast<const unsigned char*>(a.rec_grp) + (unsigned)__builtin_amdgcn_readfirstlane(tid));
-        in.ra = make_int4(g[2], 0, g[0], g[1]);
-        in.rb_ = make_float4(__int_as_float(g[4]), __int_as_float(g[5]), __int_as_float(g[6]), __int_as_float(g[7]));
-        in.rc = make_float4(__int_as_float(g[8]), __int_as_float(g[9]), __int_as_float(g[10]), __int_as_float(g[11]));
-        in.hh = make_float2(__int_as_float(g[12]), __int_as_float(g[13]));
-        in.pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
-    } else {
-        in = load_link(a, row, row, i, 0, 0, true, false, POWLAW);
+    // ---- prologue: the links' loads, issued before any LDS work or barrier (their latency overlaps pass 0)
+    LinkRaw in[LPT];
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+        const int i = tid + u * TPE;
+        if (SREC) {
+            // the records of a wave's 64 links are identical (StepArgs::rec_uniform): the whole record in one 64-byte scalar load
+            in[u].act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
+            in[u].act1 = 0;
+            const i32x16 g = scalar_load64(reinterpret_cast<const unsigned char*>(a.rec_grp) + (unsigned)(__builtin_amdgcn_readfirstlane(tid) + u * TPE));
+            in[u].ra = make_int4(g[2], 0, g[0], g[1]);
+            in[u].rb_ = make_float4(__int_as_float(g[4]), __int_as_float(g[5]), __int_as_float(g[6]), __int_as_float(g[7]));
+            in[u].rc = make_float4(__int_as_float(g[8]), __int_as_float(g[9]), __int_as_float(g[10]), __int_as_float(g[11]));
+            in[u].hh = make_float2(__int_as_float(g[12]), __int_as_float(g[13]));
+            in[u].pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
+        } else {
+            in[u] = load_link(a, row, row, i, 0, 0, true, false, POWLAW);
+        }
     }
 
-    // LDS byte addresses (StepLds): tuples at 80, the lists' slots[R] (16 bytes each) then cnt[R], flags at 64, the sums at 0
-    const unsigned L_LINK = LDS_HEAD_BYTES, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + (unsigned)R * 16u, L_EXPO = a.lds.expo;
-    const unsigned L_FLAGS = 64u, L_DUMP = 60u;                  // red[15]: where a ninth link's entry goes
-
-    // ---- pass 0: slots[R] <- EMPTY.., cnt[R] <- 0 (one contiguous region of 16-byte units), flags, the stand-in tuple
+    // ---- pass 0: slots[R + 1] <- EMPTY.., cnt[R + 1] <- 0 (one contiguous region of 16-byte units), flags, the stand-in tuple
     {
-        const int nl = R + ((R + 3) >> 2);
+        const int rows = R + 1, nl = rows + ((rows + 3) >> 2);
         const unsigned e2 = EMPTY | (EMPTY << 16);
-        if (tid < nl) { const unsigned f = tid < R ? e2 : 0u; lds_put<u32x4>(L_SLOTS + (unsigned)tid * 16u, u32x4{f, f, f, f}); }
-        if (UNLIKELY(nl > TPE)) {                                // more RBs than 0.8 N: further rounds (workgroup-uniform)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = tid + u * TPE;
+            if (k < nl) { const unsigned f = k < rows ? e2 : 0u; lds_put<u32x4>(L_SLOTS + (unsigned)k * 16u, u32x4{f, f, f, f}); }
+        }
+        if (UNLIKELY(nl > 2 * TPE)) {                            // more RBs than 1.6 threads: further rounds (workgroup-uniform)
             COLD_LOOP
-            for (int k = tid + TPE; k < nl; k += TPE) { const unsigned f = k < R ? e2 : 0u; lds_put<u32x4>(L_SLOTS + (unsigned)k * 16u, u32x4{f, f, f, f}); }
+            for (int k = tid + 2 * TPE; k < nl; k += TPE) { const unsigned f = k < rows ? e2 : 0u; lds_put<u32x4>(L_SLOTS + (unsigned)k * 16u, u32x4{f, f, f, f}); }
         }
         if (tid == TPE - 1) {
             lds_put<f32x4>(L_LINK + EMPTY, f32x4{1.0e18f, 1.0e18f, 0.0f, __int_as_float(-1)});
             if (POWLAW) lds_put<f32x2>(L_EXPO + (EMPTY >> 1), f32x2{-1.0f, 0.0f});
         }
-        if (tid < 5) lds_put<u32x4>((unsigned)tid * 16u, u32x4{0u, 0u, 0u, 0u});          // red[16] + flags[4]
+        if (tid < 5) lds_put<u32x4>((unsigned)tid * 16u, u32x4{0u, 0u, 0u, 0u});          // sum, dump, flags[4]: 80 bytes
     }
     // nothing that consumes a loaded value may be scheduled above this barrier (the wave would sit on the HBM round trip
     // before pass 0 instead of behind it)
@@ -85,84 +123,130 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- pass 1: decode (multiply-high arm only), stage the transmitter tuple, enter the RB's list
-    const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
-    const float2 rx = make_float2(in.pos.z, in.pos.w);
-    const unsigned P = __float_as_uint(in.rc.w) & 0xFFFFu;
-    // the host keeps the bound below R * P (refresh_tables): an action inside it decodes to rb < R, one beyond it (or
-    // negative: a huge unsigned) sends the workgroup down the general path
-    const bool bad = (unsigned)in.act0 > (unsigned)in.ra.w;
-    int rb = (int)__umulhi((unsigned)in.act0, (unsigned)in.ra.z);
-    int pw = in.act0 - (int)__umul24((unsigned)rb, P);
-    float4 me = make_float4(in.pos.x, in.pos.y, pow10_tenth(pw) * in.rb_.x, __int_as_float(rb));
-    const unsigned my_off = (unsigned)i << 4;
-    lds_put<f32x4>(L_LINK + my_off, f32x4{me.x, me.y, me.z, me.w});
-    if (POWLAW) lds_put<f32x2>(L_EXPO + (my_off >> 1), f32x2{in.hh.x, in.hh.y});
-    if (cfg_export_actions) { const unsigned oe = fresh((row + (unsigned)i) * 4u); RO_ST(at(a.rb_out, oe), rb); RO_ST(at(a.pwr_out, oe), pw); }
-    {
-        const unsigned rbc = min((unsigned)rb, (unsigned)(R - 1));                  // a bad lane's garbage stays inside cnt[]
-        const unsigned slot = __hip_atomic_fetch_add((D2D_LDS(unsigned)*)(L_CNT + rbc * 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_rtn_u32
+    // ---- pass 1: decode, stage the transmitter tuple, enter the RB's list
+    int rb[LPT];
+    float pz[LPT];                                               // effective tx power (mW), the tuple's third component
+    bool oor[LPT];
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+        const int i = tid + u * TPE;
+        const unsigned my_off = (unsigned)i << 4;
+        const unsigned P = __float_as_uint(in[u].rc.w) & 0xFFFFu;
+        // the host keeps the bound below R * P (refresh_tables): an action inside it decodes to rb < R by one multiply-high
+        const bool bad = (unsigned)in[u].act0 > (unsigned)in[u].ra.w;
+        rb[u] = (int)__umulhi((unsigned)in[u].act0, (unsigned)in[u].ra.z);
+        int pw = in[u].act0 - (int)__umul24((unsigned)rb[u], P);
+        oor[u] = false;
+        unsigned rbc = (unsigned)rb[u];                          // the list this link enters
+        if (UNLIKELY(__builtin_amdgcn_ballot_w64(bad) != 0ull)) {
+            if (bad) {                                           // negative, beyond R * P, or beyond the multiply-high range: divide
+                decode_link(a, in[u], row, rb[u], pw, 0, true);
+                oor[u] = (unsigned)rb[u] >= (unsigned)R;         // accepted like the reference does (d2d_env.py:94-96)
+                rbc = oor[u] ? (unsigned)R : (unsigned)rb[u];    // row R: where links that enter no list are parked
+                if (oor[u]) lds_atomic_or(L_FLAGS, FLAG_RB_OOR);
+            }
+        }
+        pz[u] = pow10_tenth(pw) * in[u].rb_.x;
+        lds_put<f32x4>(L_LINK + my_off, f32x4{in[u].pos.x, in[u].pos.y, pz[u], __int_as_float(rb[u])});
+        if (POWLAW) lds_put<f32x2>(L_EXPO + (my_off >> 1), f32x2{in[u].hh.x, in[u].hh.y});
+        if (cfg_export_actions) { const unsigned oe = fresh((row + (unsigned)i) * 4u); RO_ST(at(a.rb_out, oe), rb[u]); RO_ST(at(a.pwr_out, oe), pw); }
+        const unsigned slot = lds_atomic_inc(L_CNT + rbc * 4u);
         const bool ovf = slot >= (unsigned)RO_SLOTS;
-        const unsigned dst = ovf ? L_DUMP : L_SLOTS + rbc * 16u + slot * 2u;
-        lds_put<unsigned short>(dst, (unsigned short)my_off);
-        const bool odd = bad | ovf;
-        if (UNLIKELY(__builtin_amdgcn_ballot_w64(odd) != 0ull)) { if (odd) atomicOr(&s.flags[3], 1); }
+        lds_put<unsigned short>(ovf ? L_DUMP : L_SLOTS + rbc * 16u + slot * 2u, (unsigned short)my_off);
+        if (UNLIKELY(__builtin_amdgcn_ballot_w64(ovf) != 0ull)) {
+            if (ovf) {                                           // the ninth and later links of an RB: the env's overflow pool
+                const unsigned ps = lds_atomic_inc(L_FLAGS + 12u);
+                lds_put<u32x2>(L_POOL + ps * 8u, u32x2{(unsigned)rb[u], (unsigned)i});
+            }
+        }
     }
     __syncthreads();
-    const bool general = __builtin_amdgcn_readfirstlane(lds_get<int>(L_FLAGS + 12u)) != 0;
 
-    // software prefetch of the action row of the env the workgroup `prefetch_envs` later will own (see step_kernel)
-    int pf;
+    // software prefetch of the action rows of the env the workgroup `prefetch_envs` later will own (see step_kernel)
+    int pf = 0;
     {
         const int bq = b + a.prefetch_envs;
         const int bp = bq < a.B ? bq : a.B - 1;
-        pf = *at(a.actions, fresh(((unsigned)bp * (unsigned)N + (unsigned)i) * 4u));
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) pf ^= *at(a.actions, fresh(((unsigned)bp * (unsigned)N + (unsigned)(tid + u * TPE)) * 4u));
     }
 
-    const float rx_pl = in.rb_.y, rx_lin = in.rb_.z, noise = in.rb_.w;
-    const float sens = in.rc.x, bw_mhz = in.rc.y;
-    int dmin = 0x7F000000;                                           // power law: bits of the smallest squared distance met
-    double acc;
-    bool use_masks = false;                                          // general path: this lane walked the masks
-    uint4 mlist = make_uint4(0u, 0u, 0u, 0u);
+    float caps[LPT];
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+        const int i = tid + u * TPE;
+        const unsigned my_off = (unsigned)i << 4;
+        const int type = (in[u].ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
+        const float2 rx = make_float2(in[u].pos.z, in[u].pos.w);
+        const float rx_pl = in[u].rb_.y, rx_lin = in[u].rb_.z, noise = in[u].rb_.w;
+        const float sens = in[u].rc.x, bw_mhz = in[u].rc.y;
+        int dmin = 0x7F000000;                                   // power law: bits of the smallest squared distance met
 
-    // own link: simulator.py:93 (first: its term opens the interference sum below)
-    float d2_own, g_own;
-    {
-        const float dx = me.x - rx.x, dy = me.y - rx.y;
-        d2_own = fmaf(dx, dx, dy * dy);
-        g_own = pair_gain<MODE>(d2_own, in.hh);
-    }
+        // one (transmitter tuple at LDS offset e) -> (this receiver) term: simulator.py:97-101, linear mW
+        const auto term = [&](unsigned e, int& dmin_) {
+            const f32x4 o = lds_get<f32x4>(L_LINK + e);
+            const float dx = o.x - rx.x, dy = o.y - rx.y;
+            const float d2 = fmaf(dx, dx, dy * dy);
+            const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (e >> 1)) : make_float2(-1.0f, 0.0f));
+            if (POWLAW) dmin_ = min(dmin_, __float_as_int(d2));
+            return o.z * g;
+        };
+        // the masked all-pairs sweep in ascending link order: the reference's own loop (simulator.py:95-101), the order every
+        // other search variant reproduces; what a lane falls back to when nothing cheaper is exact
+        const auto sweep = [&](int& dmin_) {
+            double s = 0.0;
+            COLD_LOOP
+            for (int j = 0; j < N; ++j) {
+                const f32x4 o = lds_get<f32x4>(L_LINK + ((unsigned)j << 4));
+                const bool same = (__float_as_int(o.w) == rb[u]) & (j != i);
+                const float dx = o.x - rx.x, dy = o.y - rx.y;
+                const float d2 = fmaf(dx, dx, dy * dy);
+                const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + ((unsigned)j << 3)) : make_float2(-1.0f, 0.0f));
+                if (POWLAW) dmin_ = same ? min(dmin_, __float_as_int(d2)) : dmin_;
+                s += same ? (double)(o.z * g) : 0.0;
+            }
+            return s;
+        };
 
-    if (LIKELY(!general)) {
-        // ---- pass 2, fast: the RB's eight slots in one read, every slot a tuple address
-        { const u32x4 m4 = lds_get<u32x4>(L_SLOTS + (unsigned)rb * 16u); mlist = make_uint4(m4.x, m4.y, m4.z, m4.w); }
+        // own link: simulator.py:93 (first: its term opens the interference sum below)
+        float d2_own, g_own;
+        {
+            const float dx = in[u].pos.x - rx.x, dy = in[u].pos.y - rx.y;
+            d2_own = fmaf(dx, dx, dy * dy);
+            g_own = pair_gain<MODE>(d2_own, in[u].hh);
+        }
+
+        // ---- pass 2: the RB's eight slots in one read, every slot a tuple address
+        const unsigned rbc = oor[u] ? (unsigned)R : (unsigned)rb[u];
+        const u32x4 mlist = lds_get<u32x4>(L_SLOTS + rbc * 16u);
         const unsigned off[RO_SLOTS] = {mlist.x & 0xFFFFu, mlist.x >> 16, mlist.y & 0xFFFFu, mlist.y >> 16,
                                         mlist.z & 0xFFFFu, mlist.z >> 16, mlist.w & 0xFFFFu, mlist.w >> 16};
         // .difference({action}) (simulator.py:95) by arithmetic: the own entry is among the slots, so the sum opens at minus
-        // its term (me.z * g_own - the very product the slot's evaluation repeats, same operands, same rounding)
-        acc = -(double)(me.z * g_own);
+        // its term (pz * g_own - the very product the slot's evaluation repeats, same operands, same rounding)
+        const f32x2 rxv = {rx.x, rx.y};
+        double acc = -(double)(pz[u] * g_own);
         unsigned tmax = 0u, tmin = 0xFFFFFFFFu;
 #define RO_PAIR(k, o)                                                                                                   \
         {                                                                                                               \
-            const float dx = (o).x - rx.x, dy = (o).y - rx.y;                                                           \
-            const float d2 = fmaf(dx, dx, dy * dy);                                                                     \
-            const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (off[k] >> 1)) : make_float2(-1.0f, 0.0f)); \
+            const f32x2 dd = f32x2{(o).x, (o).y} - rxv;               /* one v_pk_add_f32: (x, y) sit in adjacent registers */ \
+            const float d2 = fmaf(dd.x, dd.x, dd.y * dd.y);                                                             \
+            const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (off[k] >> 1)) : make_float2(-1.0f, 0.0f));    \
             if (POWLAW) dmin = min(dmin, __float_as_int(d2));                                                           \
             const float t = (o).z * g;                               /* simulator.py:97-101, linear mW */               \
             acc += (double)t;                                                                                           \
             tmax = max(tmax, __float_as_uint(t)); tmin = min(tmin, __float_as_uint(t) - 1u);   /* zero terms: ignored */ \
         }
         {
-            const f32x4 o0 = lds_get<f32x4>(L_LINK + off[0]), o1 = lds_get<f32x4>(L_LINK + off[1]),
-                         o2 = lds_get<f32x4>(L_LINK + off[2]), o3 = lds_get<f32x4>(L_LINK + off[3]),
-                         o4 = lds_get<f32x4>(L_LINK + off[4]), o5 = lds_get<f32x4>(L_LINK + off[5]);
+            const f32x4 o0 = lds_get<f32x4>(L_LINK + off[0]), o1 = lds_get<f32x4>(L_LINK + off[1]), o2 = lds_get<f32x4>(L_LINK + off[2]),
+                        o3 = lds_get<f32x4>(L_LINK + off[3]), o4 = lds_get<f32x4>(L_LINK + off[4]), o5 = lds_get<f32x4>(L_LINK + off[5]);
             RO_PAIR(0, o0) RO_PAIR(1, o1) RO_PAIR(2, o2) RO_PAIR(3, o3) RO_PAIR(4, o4) RO_PAIR(5, o5)
             asm volatile("" ::"v"(o0.w), "v"(o1.w), "v"(o2.w), "v"(o3.w), "v"(o4.w), "v"(o5.w));   // .w kept live: ds_read_b128, not b96
         }
         // slots fill in arrival order: a seventh / eighth member exists for some lane of 2 in 3 / 1 in 4 waves
+        unsigned members = 0u;                                   // links on my RB, read only when its row is full
         if (__builtin_amdgcn_ballot_w64(off[6] != EMPTY) != 0ull) {
             const f32x4 o6 = lds_get<f32x4>(L_LINK + off[6]), o7 = lds_get<f32x4>(L_LINK + off[7]);
+            if (off[7] != EMPTY) members = lds_get<unsigned>(L_CNT + rbc * 4u);
             RO_PAIR(6, o6) RO_PAIR(7, o7)
             asm volatile("" ::"v"(o6.w), "v"(o7.w));
         }
@@ -170,179 +254,170 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // all partial sums exact <=> the sum is the ascending-order sum: largest and smallest non-zero term within 2^25
         // (nine values of 24 bits inside the 53 of a double); compared on the raw bits (conservative by less than one binade)
         const bool inexact = tmax - tmin >= (25u << 23);
-        if (UNLIKELY(__builtin_amdgcn_ballot_w64(inexact) != 0ull)) {
-            if (inexact) {
+        const bool big = members > (unsigned)RO_SLOTS;           // more members than the row holds: the rest is in the pool
+        if (UNLIKELY(__builtin_amdgcn_ballot_w64(inexact | big | oor[u]) != 0ull)) {
+            if (oor[u]) {
+                // an RB outside [0, R) has no list: whoever shares that value is found by the sweep
+                dmin = 0x7F000000;
+                acc = sweep(dmin);
+            } else if (big) {
+                // eight members in the row (own entry possibly among them), the others in the pool, tagged with their RB.  First
+                // the order-free attempt: all terms in whatever order they sit, exact inside a window of 53 - 24 - bits(members) bits
+                dmin = 0x7F000000;
+                double s = 0.0;
+                unsigned hi = 0u, lo = 0xFFFFFFFFu;
+#pragma unroll
+                for (int k = 0; k < RO_SLOTS; ++k) {
+                    if (off[k] != my_off) { const float t = term(off[k], dmin); s += (double)t; hi = max(hi, __float_as_uint(t)); lo = min(lo, __float_as_uint(t) - 1u); }
+                }
+                const unsigned pc = min(lds_get<unsigned>(L_FLAGS + 12u), (unsigned)N);
+                COLD_LOOP
+                for (unsigned p = 0; p < pc; ++p) {
+                    const u32x2 e = lds_get<u32x2>(L_POOL + p * 8u);
+                    if (e.x == (unsigned)rb[u] && e.y != (unsigned)i) {
+                        const float t = term(e.y << 4, dmin); s += (double)t; hi = max(hi, __float_as_uint(t)); lo = min(lo, __float_as_uint(t) - 1u);
+                    }
+                }
+                const unsigned window = 29u - (32u - (unsigned)__builtin_clz(members));       // 9 .. 15 members: 25 bits; 2047: 18
+                if (hi - lo >= (window << 23)) {
+                    // ... else in ascending link order.  A lane that sweeps all N pairs outlives its whole launch (20 us and more
+                    // against 3 per workgroup), so the sweep is kept for RBs where it is no worse than anything else could be;
+                    // up to 32 members: selection - the smallest member offset not yet taken, members x (8 + pool) compares
+                    dmin = 0x7F000000;
+                    if (members <= 32u) {
+                        s = 0.0;
+                        unsigned from = 0u;
+                        COLD_LOOP
+                        while (true) {
+                            unsigned best = 0xFFFFFFFFu;
+#pragma unroll
+                            for (int k = 0; k < RO_SLOTS; ++k) if (off[k] >= from && off[k] != my_off) best = min(best, off[k]);
+                            COLD_LOOP
+                            for (unsigned p = 0; p < pc; ++p) {
+                                const u32x2 e = lds_get<u32x2>(L_POOL + p * 8u);
+                                const unsigned c = e.y << 4;
+                                if (e.x == (unsigned)rb[u] && c >= from && c != my_off) best = min(best, c);
+                            }
+                            if (best == 0xFFFFFFFFu) break;
+                            s += (double)term(best, dmin);
+                            from = best + 16u;
+                        }
+                    } else s = sweep(dmin);
+                }
+                acc = s;
+            } else if (inexact) {
                 unsigned v[RO_SLOTS];
 #pragma unroll
                 for (int k = 0; k < RO_SLOTS; ++k) v[k] = off[k] == my_off ? 0xFFFFu : off[k];   // own entry out; sorts last
                 sort8(v);
-                double acc2 = 0.0;
+                double s = 0.0;
+                int dummy = 0;
                 COLD_LOOP
                 for (int k = 0; k < RO_SLOTS - 1; ++k) {
                     if (v[k] >= EMPTY) break;
-                    const f32x4 o = lds_get<f32x4>(L_LINK + v[k]);
-                    const float dx = o.x - rx.x, dy = o.y - rx.y;
-                    const float d2 = fmaf(dx, dx, dy * dy);
-                    const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (v[k] >> 1)) : make_float2(-1.0f, 0.0f));
-                    acc2 += (double)(o.z * g);
+                    s += (double)term(v[k], dummy);
                 }
-                acc = acc2;
+                acc = s;
             }
         }
-    } else {
-        // ---- pass 2, general (a workgroup in which some lane met a rarity): exact decode, tuples rewritten, membership masks
-        // built behind two more barriers, nested mask walk; a lane whose own rb lies outside [0, R) sweeps all pairs.  The
-        // generic kernel's code (d2d_step.hip), cost proportional to the same-RB pairs for any action distribution.
-        {
-            int rb2, p2;
-            decode_link(a, in, row, rb2, p2, 0, true);
-            rb = rb2; pw = p2;
-            me = make_float4(in.pos.x, in.pos.y, pow10_tenth(pw) * in.rb_.x, __int_as_float(rb));
-            s.link[i] = me;
-            if (cfg_export_actions) { const unsigned oe = fresh((row + (unsigned)i) * 4u); RO_ST(at(a.rb_out, oe), rb); RO_ST(at(a.pwr_out, oe), pw); }
-        }
-        clear_masks<true>(s, R, W, tid, TPE);
-        __syncthreads();
-        const bool in_range = (unsigned)rb < (unsigned)R;
-        if (in_range) {
-            atomicOr(&s.mask[__umul24((unsigned)(i >> 5), (unsigned)R) + (unsigned)rb], 1u << (i & 31));
-            atomicOr(&s.summ[rb], 1u << (i >> 5));
-        } else atomicOr(&s.flags[0], FLAG_RB_OOR);
-        __syncthreads();
-        use_masks = in_range;
-        acc = 0.0;
-        if (in_range) {
-            unsigned live = s.summ[rb];
-            const int iw = i >> 5;
-            const unsigned self = 1u << (i & 31);
-            if (live) {
-                int w = __builtin_ctz(live);
-                live &= live - 1u;
-                const unsigned R4 = (unsigned)R * 4u;
-                const unsigned char* mrow_b = reinterpret_cast<const unsigned char*>(s.mask + rb);
-                unsigned bits = *reinterpret_cast<const unsigned*>(mrow_b + __umul24((unsigned)w, R4));
-                while (true) {
-                    const bool more = live != 0u;
-                    const int wn = more ? __builtin_ctz(live) : w;
-                    const unsigned bits_n = *reinterpret_cast<const unsigned*>(mrow_b + __umul24((unsigned)wn, R4));
-                    if (w == iw) bits &= ~self;                      // .difference({action}), simulator.py:95
-                    while (bits) {
-                        const int j = (w << 5) + __builtin_ctz(bits);
-                        bits &= bits - 1u;
-                        const float4 o = s.link[j];
-                        const float dx = o.x - rx.x, dy = o.y - rx.y;
-                        const float d2 = fmaf(dx, dx, dy * dy);
-                        const float g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f));
-                        if (POWLAW) dmin = min(dmin, __float_as_int(d2));
-                        acc += (double)(o.z * g);
-                    }
-                    if (!more) break;
-                    live &= live - 1u;
-                    w = wn;
-                    bits = bits_n;
-                }
-            }
-        } else {
-            COLD_LOOP
-            for (int j = 0; j < N; ++j) {
-                const float4 o = s.link[j];
-                const bool same = (__float_as_int(o.w) == rb) & (j != i);
-                const float dx = o.x - rx.x, dy = o.y - rx.y;
-                const float d2 = fmaf(dx, dx, dy * dy);
-                const float g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f));
-                if (POWLAW) dmin = same ? min(dmin, __float_as_int(d2)) : dmin;
-                acc += same ? (double)(o.z * g) : 0.0;
-            }
-        }
-    }
 
-    // ---- SINR / SNR / rate / capacity: the arithmetic of step_kernel, operation for operation
-    if (POWLAW) dmin = min(dmin, __float_as_int(d2_own));
-    const float sig = me.z * g_own * rx_pl * rx_lin;                 // mW at the receiver, with rx gains
-    const float accf = (float)acc;
-    // interferers: no rx gains (simulator.py:100); the fma every kernel's `accf * rx_pl + noise` contracted to, spelled out
-    const float sinr_lin = precise_div(sig, fmaf(accf, rx_pl, noise));
-    const float sinr_db = 3.01029995663981195f * __builtin_amdgcn_logf(sinr_lin);                 // simulator.py:106-107
-    const float snr_db = 3.01029995663981195f * __builtin_amdgcn_logf(precise_div(sig, noise));   // simulator.py:115
-    const float u1p = 1.0f + sinr_lin, um1 = u1p - 1.0f;
-    const float sh_big = __builtin_amdgcn_logf(u1p) * fast_div(sinr_lin, um1 == 0.0f ? 1.0f : um1);
-    const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f : sh_big;
-    const bool ok = sinr_db > sens;                                  // simulator.py:123,149
-    const float rate = ok ? sh : 0.0f;
-    const float cap = ok ? bw_mhz * sh : 0.0f;                       // simulator.py:150-151
-    {
-        const unsigned o4 = fresh((row + (unsigned)i) * 4u);
-        RO_ST(at(a.sinr_db, o4), sinr_db);
-        RO_ST(at(a.snr_db, o4), snr_db);
-        RO_ST(at(a.rate, o4), rate);
-        RO_ST(at(a.cap, o4), cap);
-    }
-    if (a.write_table) {                                             // obs_fn.py:57-60
-        const unsigned o4t = fresh((row + (unsigned)i) * 4u);
-        float2* t = reinterpret_cast<float2*>(at(a.table, (o4t << 2) + (o4t << 1)));
-        if (NT) {
-            f32x2* tv = reinterpret_cast<f32x2*>(t);
-            const f32x2 v0 = {me.x, me.y}, v1 = {rx.x, rx.y}, v2 = {sinr_db, snr_db};
-            __builtin_nontemporal_store(v0, tv); __builtin_nontemporal_store(v1, tv + 1); __builtin_nontemporal_store(v2, tv + 2);
-        } else {
-            t[0] = make_float2(me.x, me.y);
-            t[1] = rx;
-            t[2] = make_float2(sinr_db, snr_db);
+        // ---- SINR / SNR / rate / capacity: the arithmetic of step_kernel, operation for operation
+        if (POWLAW) dmin = min(dmin, __float_as_int(d2_own));
+        const float sig = pz[u] * g_own * rx_pl * rx_lin;            // mW at the receiver, with rx gains
+        const float accf = (float)acc;
+        // interferers: no rx gains (simulator.py:100); the fma every kernel's `accf * rx_pl + noise` contracted to, spelled out
+        const float sinr_lin = precise_div(sig, fmaf(accf, rx_pl, noise));
+        const float sinr_db = 3.01029995663981195f * __builtin_amdgcn_logf(sinr_lin);                 // simulator.py:106-107
+        const float snr_db = 3.01029995663981195f * __builtin_amdgcn_logf(precise_div(sig, noise));   // simulator.py:115
+        const float u1p = 1.0f + sinr_lin, um1 = u1p - 1.0f;
+        const float sh_big = __builtin_amdgcn_logf(u1p) * fast_div(sinr_lin, um1 == 0.0f ? 1.0f : um1);
+        const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f : sh_big;
+        const bool ok = sinr_db > sens;                              // simulator.py:123,149
+        const float rate = ok ? sh : 0.0f;
+        const float cap = ok ? bw_mhz * sh : 0.0f;                   // simulator.py:150-151
+        {
+            const unsigned o4 = fresh((row + (unsigned)i) * 4u);
+            RO_ST(at(a.sinr_db, o4), sinr_db);
+            RO_ST(at(a.snr_db, o4), snr_db);
+            RO_ST(at(a.rate, o4), rate);
+            RO_ST(at(a.cap, o4), cap);
+        }
+        if (a.write_table) {                                         // obs_fn.py:57-60
+            const unsigned o4t = fresh((row + (unsigned)i) * 4u);
+            float2* t = reinterpret_cast<float2*>(at(a.table, (o4t << 2) + (o4t << 1)));
+            if (NT) {
+                f32x2* tv = reinterpret_cast<f32x2*>(t);
+                const f32x2 v0 = {in[u].pos.x, in[u].pos.y}, v1 = {rx.x, rx.y}, v2 = {sinr_db, snr_db};
+                __builtin_nontemporal_store(v0, tv); __builtin_nontemporal_store(v1, tv + 1); __builtin_nontemporal_store(v2, tv + 2);
+            } else {
+                t[0] = make_float2(in[u].pos.x, in[u].pos.y);
+                t[1] = rx;
+                t[2] = make_float2(sinr_db, snr_db);
+            }
+        }
+        caps[u] = cap;
+
+        // per-lane rarities behind ONE wave-uniform branch: SystemCapacity's -1 rule (reward_fn.py:29-41: I am a non-D2D link whose
+        // capacity is <= min_capacity and some D2D link shares my RB), a non-finite SINR / zero distance, a capacity too large for
+        // the fixed-point sum (64 lanes x 3e7 stays below the 4e9 a 32.32 value holds)
+        const bool rule = type != LINK_SIDELINK && cap <= a.reward_param;
+        const bool nonfinite = MODE == PL_INV_SQUARE ? !(fabsf(sinr_db) <= 3.0e38f) : (dmin == 0 || !(fabsf(sinr_db) <= 3.0e38f));
+        const bool huge = !(cap <= 3.0e7f);
+        if (UNLIKELY(__builtin_amdgcn_ballot_w64(rule | nonfinite | huge) != 0ull)) {
+            if (rule) {
+                bool hit = false;
+                const auto sidelink = [&](unsigned j) { return ((a.side_words[j >> 5] >> (j & 31u)) & 1u) != 0u; };
+                if (oor[u]) {
+                    COLD_LOOP
+                    for (int k = 0; k < N; ++k)
+                        hit |= (k != i) & sidelink((unsigned)k) & (__float_as_int(lds_get<f32x4>(L_LINK + ((unsigned)k << 4)).w) == rb[u]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < RO_SLOTS; ++k)
+                        if (off[k] != EMPTY && off[k] != my_off) hit |= sidelink(off[k] >> 4);
+                    if (big) {
+                        const unsigned pc = min(lds_get<unsigned>(L_FLAGS + 12u), (unsigned)N);
+                        COLD_LOOP
+                        for (unsigned p = 0; p < pc; ++p) {
+                            const u32x2 e = lds_get<u32x2>(L_POOL + p * 8u);
+                            if (e.x == (unsigned)rb[u] && e.y != (unsigned)i) hit |= sidelink(e.y);
+                        }
+                    }
+                }
+                if (hit) lds_atomic_or(L_FLAGS + 4u, 1);
+            }
+            int my_flags = 0;
+            if (MODE == PL_INV_SQUARE) {
+                // 1 / d^2 gains: a zero distance (own link: signal inf; an interferer: accumulator inf) always ends in a non-finite SINR
+                if (nonfinite) { my_flags |= FLAG_NON_FINITE; if (d2_own == 0.0f || !(accf <= 3.0e38f)) my_flags |= FLAG_ZERO_DISTANCE; }
+            } else {
+                if (dmin == 0) my_flags |= FLAG_ZERO_DISTANCE;
+                if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
+            }
+            if (my_flags) lds_atomic_or(L_FLAGS, my_flags);
+            // a non-finite (or absurdly large) capacity cannot go through the fixed-point accumulator: the env's reward is then what
+            // a float sum gives - inf, or NaN once a NaN is among the parts
+            if (huge) lds_atomic_or(L_FLAGS + 4u, cap != cap ? 4 : 2);
         }
     }
 
     // ---- reward: barrier-free ticket reduction (see step_kernel): DPP wave sum, 32.32 fixed-point capacity total in LDS (the
     // 64-bit integer sum does not depend on arrival order), the wave that draws the last ticket finishes the env
     const int lane = tid & 63;
-    const float wsum = wave_sum(cap);
-    // per-lane rarities behind ONE wave-uniform branch: SystemCapacity's -1 rule (reward_fn.py:29-41: I am a non-D2D link whose
-    // capacity is <= min_capacity and some D2D link shares my RB), a non-finite SINR / zero distance, a capacity too large
-    // for the fixed-point sum (64 lanes x 6e7 stays below the 4e9 the accumulator takes per wave: no test of the sum outside)
-    const bool rule = type != LINK_SIDELINK && cap <= a.reward_param;
-    const bool nonfinite = MODE == PL_INV_SQUARE ? !(fabsf(sinr_db) <= 3.0e38f) : (dmin == 0 || !(fabsf(sinr_db) <= 3.0e38f));
-    const bool huge = !(cap <= 6.0e7f);
-    bool add_sum = true;                                             // wave-uniform
-    if (UNLIKELY(__builtin_amdgcn_ballot_w64(rule | nonfinite | huge) != 0ull)) {
-        if (rule) {
-            bool hit = false;
-            if (!general) {
-                const unsigned words[4] = {mlist.x, mlist.y, mlist.z, mlist.w};
+    // one DPP sum per GROUP OF 64 LINKS (LPT = 2: two per wave - links t.. and t + N/2..), each converted to fixed point on its own:
+    // the float roundings are those of the one-link-per-thread kernels' wave sums, so the env's total has the same bits whatever LPT
+    unsigned long long fixed = 0ull;
 #pragma unroll
-                for (int k = 0; k < RO_SLOTS; ++k) {
-                    const unsigned e = (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, j = e >> 4;
-                    if (e != EMPTY && j != (unsigned)i) hit |= ((a.side_words[j >> 5] >> (j & 31u)) & 1u) != 0u;
-                }
-            } else if (use_masks) {
-                COLD_LOOP
-                for (int w = 0; w < W; ++w) hit |= (s.mask[(unsigned)w * (unsigned)R + (unsigned)rb] & a.side_words[w]) != 0u;
-            } else {
-                COLD_LOOP
-                for (int k = 0; k < N; ++k)
-                    hit |= (k != i) & (((a.rec_a[k].x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK) == LINK_SIDELINK) &
-                           (__float_as_int(s.link[k].w) == rb);
-            }
-            if (hit) atomicOr(&s.flags[1], 1);
-        }
-        int my_flags = 0;
-        if (MODE == PL_INV_SQUARE) {
-            // 1 / d^2 gains: a zero distance (own link: signal inf; an interferer: accumulator inf) always ends in a non-finite SINR
-            if (nonfinite) { my_flags |= FLAG_NON_FINITE; if (d2_own == 0.0f || !(accf <= 3.0e38f)) my_flags |= FLAG_ZERO_DISTANCE; }
-        } else {
-            if (dmin == 0) my_flags |= FLAG_ZERO_DISTANCE;
-            if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
-        }
-        if (my_flags) atomicOr(&s.flags[0], my_flags);
-        // a non-finite (or absurdly large) wave sum cannot go through the fixed-point accumulator: the env's reward is then what
-        // a float sum gives - inf, or NaN once a NaN is among the parts
-        if (!(wsum <= 4.0e9f)) { add_sum = false; atomicOr(&s.flags[1], wsum != wsum ? 4 : 2); }
-    }
-    asm volatile("" ::"v"(pf));                                      // the prefetched word is consumed here (no instruction)
+    for (int u = 0; u < LPT; ++u) fixed += to_fixed_32_32(wave_sum(caps[u]));
+    asm volatile("" ::"v"(pf));                                      // the prefetched words are consumed here (no instruction)
     // This wave's LDS atomics above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
     // above it in the instruction stream.  The last wave's reads below stay behind its own ticket (acquire).
     asm volatile("" ::: "memory");
     int ticket = 0;
     if (lane == 0) {
-        if (add_sum) __hip_atomic_fetch_add((D2D_LDS(unsigned long long)*)(0u), to_fixed_32_32(wsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (a wave with a huge / non-finite capacity has raised bits 2 / 4 of flags[1]: the total is then not read, whatever
+        // v_cvt_u32_f32's saturation made of this sum)
+        __hip_atomic_fetch_add((D2D_LDS(unsigned long long)*)(0u), fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
         ticket = __hip_atomic_fetch_add((D2D_LDS(int)*)(L_FLAGS + 8u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -350,9 +425,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (ticket == (TPE >> 6) - 1) {
         // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone on a violation
-        const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long*>(s.red), 0ull);   // LDS read that cannot be hoisted
+        const unsigned long long tot = __hip_atomic_fetch_add((D2D_LDS(unsigned long long)*)(0u), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // an LDS read that cannot be hoisted
         const float total = (float)tot * 2.3283064365386963e-10f;
-        const int viol = atomicOr(&s.flags[1], 0);
+        const int viol = __hip_atomic_fetch_or((D2D_LDS(int)*)(L_FLAGS + 4u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const float r = (viol & 1) ? -1.0f : ((viol & 4) ? __int_as_float(0x7FC00000) : ((viol & 2) ? __int_as_float(0x7F800000) : total * a.inv_n));
         if (a.reward_env) {                                            // D2D_REWARD_PER_ENV: the scalar once, not N copies
             if (lane == 0) a.reward_env[b] = r;
@@ -360,32 +435,42 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             const f32x4 r4 = {r, r, r, r};
             for (int k = lane * 4; k < N; k += 256) RO_ST(reinterpret_cast<f32x4*>(at(a.reward, fresh((row + (unsigned)k) * 4u))), r4);
         }
-        if (lane == 0) a.env_flags[b] = atomicOr(&s.flags[0], 0);
+        if (lane == 0) a.env_flags[b] = __hip_atomic_fetch_or((D2D_LDS(int)*)(L_FLAGS), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, size_t lds, hipStream_t stream) {
+hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, hipStream_t stream) {
     dim3 grid((unsigned)a.B), block(block_threads);
+    const size_t lds = a.lds.env_bytes;
     hipError_t err = hipSuccess;
-#define D2D_RO_1(M, O)                                                                                   \
+#define D2D_RO_1(M, O, L)                                                                                \
     do {                                                                                                 \
-        if (lds > 48 * 1024)                                                                             \
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<M, O>),              \
+        static int checked = 0;                                                                          \
+        if (!checked) {                                 /* raw LDS addressing: the dynamic block must start at LDS address 0 */ \
+            hipFuncAttributes fa;                                                                        \
+            err = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&rollout_kernel<M, O, L>));    \
+            if (err == hipSuccess && fa.sharedSizeBytes != 0) err = hipErrorInvalidConfiguration;        \
+            if (err == hipSuccess) checked = 1;                                                          \
+        }                                                                                                \
+        if (err == hipSuccess && lds > 48 * 1024)                                                        \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<M, O, L>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         if (err == hipSuccess) {                                                                         \
-            hipLaunchKernelGGL((rollout_kernel<M, O>), grid, block, lds, stream, a);                     \
+            hipLaunchKernelGGL((rollout_kernel<M, O, L>), grid, block, lds, stream, a);                  \
             err = hipGetLastError();                                                                     \
         }                                                                                                \
     } while (0)
-#define D2D_RO(M)                                                                                        \
+#define D2D_RO_L(M, L)                                                                                   \
     switch (opt & (OPT_SREC | OPT_NT)) {                                                                 \
-        case 0: D2D_RO_1(M, 0); break;                                                                   \
-        case OPT_SREC: D2D_RO_1(M, OPT_SREC); break;                                                     \
-        case OPT_NT: D2D_RO_1(M, OPT_NT); break;                                                         \
-        default: D2D_RO_1(M, OPT_SREC | OPT_NT); break;                                                  \
+        case 0: D2D_RO_1(M, 0, L); break;                                                                \
+        case OPT_SREC: D2D_RO_1(M, OPT_SREC, L); break;                                                  \
+        case OPT_NT: D2D_RO_1(M, OPT_NT, L); break;                                                      \
+        default: D2D_RO_1(M, OPT_SREC | OPT_NT, L); break;                                               \
     }
-    if (mode == PL_INV_SQUARE) { D2D_RO(PL_INV_SQUARE) } else { D2D_RO(PL_POWER) }
+#define D2D_RO(M) do { if (a.lpt == 2) { D2D_RO_L(M, 2) } else { D2D_RO_L(M, 1) } } while (0)
+    if (mode == PL_INV_SQUARE) D2D_RO(PL_INV_SQUARE); else D2D_RO(PL_POWER);
 #undef D2D_RO
+#undef D2D_RO_L
 #undef D2D_RO_1
     return err;
 }

@@ -177,7 +177,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     // before pass 0 instead of behind it
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
-    if (!ABL(64)) __syncthreads();
+    // Envs of one wave each (HOT level 2 at N <= 64: BASELINE config 2): what passes 0 - 2 share through LDS belongs to ONE wave,
+    // whose LDS operations complete in issue order - no workgroup barrier is needed until the reward pass publishes the tables
+    // for the expansion (two of the kernel's three barriers; 0.35 us of a 13.4 us step, r4_phase_times_default_fused_kernel.json)
+    const bool solo = HOT == 2 && TPE == 64;
+#define PASS_BARRIER() do { if (solo) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); } while (0)
+    if (!ABL(64)) PASS_BARRIER();
     STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
     if (ABL(256)) {                       // diagnostic: launch + prologue loads + pass 0 only
@@ -198,8 +203,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float4 tuple = make_float4(in.pos.x, in.pos.y, pow10_tenth(p) * in.rb_.x, __int_as_float(rb));
         s.link[i] = tuple;
         if (LPT == 0) s.rx[i] = make_float2(in.pos.z, in.pos.w);
-        if (!HOT) s.aux[i] = in.ra.x & 0x0FFFFFFF;                       // tx_dev | link_type << 24 (HOT: only the cold all-pairs
-                                                                         // route wants the type, and reads it from the record)
+        // tx_dev | link_type << 24 (HOT: only the cold all-pairs route wants the type, and reads it from the record); the low bits
+        // are the transmitter's ROW in the gain table: its device, or - a table by (tx link, rx link) - the link itself
+        if (!HOT) s.aux[i] = MODE == PL_TABLE && a.table_by_link ? (i | (in.ra.x & 0x0F000000)) : (in.ra.x & 0x0FFFFFFF);
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (POWLAW) s.expo[i] = in.hh;
         if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); ST(at(a.rb_out, oe), rb); ST(at(a.pwr_out, oe), p); }
@@ -226,7 +232,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         } else if (!LISTS && UNLIKELY((unsigned)rb >= (unsigned)R)) atomicOr(&s.flags[0], FLAG_RB_OOR);   // all-pairs sweep: flagged all the same
     }
     STAMP(3);
-    if (!ABL(64)) __syncthreads();
+    if (!ABL(64)) PASS_BARRIER();
+#undef PASS_BARRIER
     STAMP(4);
     // LISTS: did any RB of any env of this workgroup draw a ninth link?  Then every env of the workgroup builds its masks now
     // (two more barriers, workgroup-uniform) and walks them instead.
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float dx = (o).x - rx.x, dy = (o).y - rx.y;                                                       \
                 const float d2 = fmaf(dx, dx, dy * dy);                                                                 \
                 float g;                                                                                                \
-                if (MODE == PL_TABLE) g = gtab[(size_t)(a.table_by_link ? (int)(j) : (s.aux[j] & 0xFFFFFF)) * a.table_pitch + tcol];                                \
+                if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];                                \
                 else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); } \
                 if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, (int)(j), i, 0u);              \
                 acc += (double)((o).z * g);                              /* simulator.py:97-101, linear mW */            \
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         const float dx = o.x - rx.x, dy = o.y - rx.y;
                         const float d2 = fmaf(dx, dx, dy * dy);
                         float g;
-                        if (MODE == PL_TABLE) g = gtab[(size_t)(a.table_by_link ? (int)(j) : (s.aux[j] & 0xFFFFFF)) * a.table_pitch + tcol];
+                        if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];
                         else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                         acc += (double)(o.z * g);                        // simulator.py:97-101, linear mW
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                             const float dx = o.x - rx.x, dy = o.y - rx.y;
                             const float d2 = fmaf(dx, dx, dy * dy);
                             float g;
-                            if (MODE == PL_TABLE) g = gtab[(size_t)(a.table_by_link ? (int)(j) : (s.aux[j] & 0xFFFFFF)) * a.table_pitch + tcol];
+                            if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];
                             else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
                             if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                             acc += (double)(o.z * g);                    // simulator.py:97-101, linear mW
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float dx = o.x - rx.x, dy = o.y - rx.y;
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
-                if (MODE == PL_TABLE) g = same ? gtab[(size_t)(a.table_by_link ? (int)(j) : (s.aux[j] & 0xFFFFFF)) * a.table_pitch + tcol] : 0.0f;
+                if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol] : 0.0f;
                 else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
                 if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                 acc += same ? (double)(o.z * g) : 0.0;
@@ -830,8 +837,8 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
                      (a.walk == 0 || lists) && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
     const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0);
-    // the rollout configuration with member lists has a kernel of its own (d2d_rollout.hip)
-    if (lpt == 1 && full && hot && lists) return launch_rollout(a, mode, hot_opt, block_threads, lds, stream);
+    // the rollout configuration with member lists has a kernel of its own (d2d_rollout.hip; chosen by run_step)
+    if (a.rollout) return launch_rollout(a, mode, hot_opt, block_threads, stream);
     // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&

@@ -319,6 +319,9 @@ int d2d_profile_enable(d2d_handle* h, int32_t enabled);
 /* kernel: 0 = step (decode+SINR+reward+table), 1 = LinearObs expansion.  Synchronises, then returns
  * accumulated device time in ms and launch count since the last reset.                             */
 int d2d_profile_read(d2d_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+/* Median duration (ms) of that kernel's launches since the last reset (the first 65536 of them): the figure a
+ * roofline is quoted on beside the mean, which a cold first launch or a clock ramp pulls up.               */
+int d2d_profile_median(d2d_handle* h, int32_t kernel, double* median_ms);
 int d2d_profile_reset(d2d_handle* h);
 
 #ifdef __cplusplus

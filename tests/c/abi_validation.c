@@ -70,6 +70,7 @@ int main(void) {
     EXPECT_ERR(d2d_profile_enable(NULL, 1));
     EXPECT_ERR(d2d_profile_read(NULL, 0, &rate, &launches));
     EXPECT_ERR(d2d_profile_reset(NULL));
+    EXPECT_ERR(d2d_profile_median(NULL, 0, &rate));
     if (d2d_destroy(NULL) != D2D_OK) { fprintf(stderr, "d2d_destroy(NULL) must be a no-op\n"); ++failures; }
 
     /* d2d_create: every field that can be wrong */
@@ -140,6 +141,7 @@ int main(void) {
     EXPECT_ERR(d2d_allgather(h, fone, fone, 4, NULL));               /* no communicator */
     EXPECT_ERR(d2d_comm_init(h, 2, 5, id));
     EXPECT_ERR(d2d_profile_read(h, 7, &rate, &launches));
+    EXPECT_ERR(d2d_profile_median(h, 2, &rate));
     EXPECT_ERR(d2d_set_path_loss_link_table(h, one, 2, 0));          /* before d2d_set_links */
     EXPECT_ERR(d2d_set_tuning(h, 9 /* D2D_TUNE_STEP_ABLATE, d2d_hip_diag.h */, 1));   /* release build: diagnostic keys refused */
     EXPECT_ERR(d2d_set_tuning(h, D2D_TUNE_STEP_WALK, 1));           /* the flattened walk: diagnostic builds only */

@@ -29,3 +29,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope='module')
+def native():
+    """gym_d2d_amd._native with the library loaded (raises if libd2d_hip.so is missing: there is no CPU fallback)."""
+    from gym_d2d_amd import _native
+    _native.load_library()
+    return _native

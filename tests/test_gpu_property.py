@@ -38,7 +38,7 @@ def scenarios(draw):
     n_over = draw(st.integers(0, 3))
     use_downlinks = draw(st.booleans()) and cues > 0
     explicit = draw(st.booleans())
-    walk = draw(st.sampled_from([-1, 0, 1, 2]))       # interferer search: auto / mask walk nested / flattened / member lists
+    walk = draw(st.sampled_from([-1, 0, 2]))          # interferer search: auto / mask walk / member lists (the flattened walk: diagnostic builds)
     return dict(walk=walk, big=big, rbs=rbs, cues=cues, dues=dues, envs=envs, seed=seed, model=model, ple=ple, reward=reward,
                 reward_param=reward_param, n_over=n_over, use_downlinks=use_downlinks, explicit=explicit)
 

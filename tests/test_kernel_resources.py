@@ -65,6 +65,37 @@ def test_strided_and_shadowing_kernels_stay_within_a_few_lane_spills(kernels):
             assert k['sgpr_spills'] < 32, ((mode, lpt, full, hot, opt), k)
 
 
+@pytest.fixture(scope='module')
+def rollout_kernels(tmp_path_factory):
+    from gym_d2d_amd import build
+    tmp = tmp_path_factory.mktemp('isa_rollout')
+    cmd = [build._hipcc(), *build.FLAGS, '-I', str(build.INCLUDE), '-c', str(build.CSRC / 'd2d_rollout.hip'), '-save-temps', '-o', 'ro.o']
+    r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    asm = next(tmp.glob('*gfx950*.s')).read_text()
+    out = {}
+    for blk in re.split(r'\n  - ', asm[asm.find('amdhsa.kernels'):]):
+        name = re.search(r'\.name:\s+(\S+)', blk)
+        m = name and re.match(r'_ZN3d2d14rollout_kernelILi(\d)ELi(\d)ELi(\d)EEEvNS_8StepArgsE', name.group(1))
+        if m:
+            field = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, blk).group(1))
+            out[tuple(int(x) for x in m.groups())] = {'vgpr': field('vgpr_count'), 'sgpr_spills': field('sgpr_spill_count'),
+                                                      'vgpr_spills': field('vgpr_spill_count'), 'scratch': field('private_segment_fixed_size'),
+                                                      'static_lds': field('group_segment_fixed_size')}
+    assert len(out) == 16, sorted(out)
+    return out
+
+
+def test_rollout_kernel_of_round5_keeps_full_occupancy_and_no_static_lds(rollout_kernels):
+    """csrc/d2d_rollout.hip, <path-loss mode, options, links per thread>: nothing spills; with scalar records (option bit 2: what
+    BASELINE configs 3 - 5 run) one and two links per thread stay within 64 VGPRs = 8 waves per SIMD; no static LDS in front of
+    the dynamic block (the kernel addresses LDS by raw byte offsets)."""
+    for key, k in rollout_kernels.items():
+        assert k['scratch'] == 0 and k['vgpr_spills'] == 0 and k['sgpr_spills'] == 0 and k['static_lds'] == 0, (key, k)
+        if key[1] & 2:
+            assert k['vgpr'] <= 64, (key, k)
+
+
 def test_rollout_kernel_keeps_full_occupancy(kernels):
     """8 waves per SIMD (four 512-thread workgroups per CU) needs <= 64 VGPRs; the scalar-record variant holds the records in
     SGPRs and frees vector registers."""

@@ -39,13 +39,14 @@ def prepare(names):
         print('built', out.name)
 
 
-def one(lib, workload, export=True, mode='table', walk=-1):
+def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools'))
     from gym_d2d_amd import _native
     _native.LIB_PATH = Path(lib).resolve()
     # an older build lacks the newer entry points: drop them from the binding (this tool only) and make their wrappers no-ops
     import ctypes
     probe = ctypes.CDLL(str(_native.LIB_PATH))
+    _native.ABI_VERSION = probe.d2d_abi_version()            # an older build: its own ABI number (the calls this tool makes exist in all)
     for name in [n for n in _native.SIGNATURES if not hasattr(probe, n)]:
         del _native.SIGNATURES[name]
         setattr(_native.Handle, name[len('d2d_'):], lambda self, *a, **k: None)
@@ -69,15 +70,17 @@ def one(lib, workload, export=True, mode='table', walk=-1):
     h.set_export_actions(export)
     if walk >= 0:
         h.set_tuning(_native.TUNE_STEP_WALK, walk)
+    if lpt > 0:
+        h.set_tuning(_native.TUNE_STEP_LPT, lpt)
     act = torch.randint(0, r * 21, (64, b, cols), device=env.device, dtype=torch.int32)
     t = [timed(h, act, 32) for _ in range(15)]
-    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'obs': mode, 'walk': walk, 'export_rb_pwr': int(export), 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
+    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'obs': mode, 'walk': walk, 'lpt': lpt, 'export_rb_pwr': int(export), 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
 
 
-def run(workload, passes, export=True, mode='table', walk=-1):
+def run(workload, passes, export=True, mode='table', walk=-1, lpt=-1):
     for k in range(passes):
         for lib in sorted(LIBS.glob('*.so')):
-            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload, '--mode', mode, '--walk', str(walk)] + ([] if export else ['--no-export']),
+            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload, '--mode', mode, '--walk', str(walk), '--lpt', str(lpt)] + ([] if export else ['--no-export']),
                                capture_output=True, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             print(line[-1] if line else f'{lib.name}: failed {r.stderr[-300:]}', flush=True)
@@ -91,11 +94,12 @@ if __name__ == '__main__':
     ap.add_argument('--passes', type=int, default=2)
     ap.add_argument('--mode', default='table', choices=['table', 'none'], help='stress: compact table (OwnLinkObs) or the obs-less learner mode')
     ap.add_argument('--walk', type=int, default=-1, help='D2D_TUNE_STEP_WALK (-1 = the library default)')
+    ap.add_argument('--lpt', type=int, default=-1, help='D2D_TUNE_STEP_LPT (-1 = the library default)')
     ap.add_argument('--no-export', action='store_true', help='d2d_set_export_actions(0): no decoded rb / pwr planes')
     a = ap.parse_args()
     if a.what == 'prepare':
         prepare(a.names)
     elif a.what == 'run':
-        run(a.workload, a.passes, not a.no_export, a.mode, a.walk)
+        run(a.workload, a.passes, not a.no_export, a.mode, a.walk, a.lpt)
     else:
-        one(a.names[0], a.workload, not a.no_export, a.mode, a.walk)
+        one(a.names[0], a.workload, not a.no_export, a.mode, a.walk, a.lpt)

@@ -5,7 +5,7 @@
                                        # variant of round 2 lives in git history; its A/B is profiles/r2_ab_step_variants_stress.jsonl)
     python tools/ab_step.py ablate     # diagnostic build only (D2D_BUILD_DIAG=1): parts of the kernel skipped
     python tools/ab_step.py default    # 1024 x 50, LinearObs: envs per workgroup x fused obs x block size
-    python tools/ab_step.py wall       # 1024 x 50: wall-clock per step (no per-launch events), fused vs two launches
+    python tools/ab_step.py halves     # 1024 x 50: one env of 1024 vs two of 512 on one / two streams (wall clock per 1024 env-steps)
 
 Prints one JSON line per variant; `--out file` also appends them to a file (profiles/r2_ab_*.jsonl are these).
 """
@@ -67,7 +67,7 @@ def stress(args):
     # that put exactly two links on every RB (no imbalance between the lanes of a wave).
     variants = [(1, name, ex) for name in ('plain', 'srec', 'nt', 'srec_nt') for ex in (1, 0)]
     if not args.quick:
-        variants += [(rw, name, 1) for rw in (0, 2, 3) for name in ('srec_nt', 'member_lists', 'mask_walk_flat')]
+        variants += [(rw, name, 1) for rw in (0, 2, 3) for name in ('srec_nt', 'member_lists')]
         variants += [(1, 'member_lists', 1), (1, 'all_pairs', 1), (1, 'srec_nt_two_per_rb', 1)]
     pc, pd = env.num_pwr_actions['cue'], env.num_pwr_actions['due']
     two = torch.cat([torch.arange(c, device=env.device, dtype=torch.int32) * pc + 3,
@@ -80,7 +80,7 @@ def stress(args):
             h.set_reward(v[0], {0: 0.0, 1: 0.0, 2: -70.0, 3: 0.0}[v[0]])
             h.set_bucketing(v[1] != 'all_pairs')
             h.set_export_actions(bool(v[2]))
-            h.set_tuning(_native.TUNE_STEP_WALK, 1 if v[1] == 'mask_walk_flat' else (2 if v[1].startswith('member_lists') else 0))
+            h.set_tuning(_native.TUNE_STEP_WALK, 2 if v[1].startswith('member_lists') else 0)
             h.set_tuning(_native.TUNE_STEP_SCALAR_RECORDS, int('srec' in v[1]))
             h.set_tuning(_native.TUNE_STEP_NT_RESULTS, int('nt' in v[1]))
             times[v].append(timed(h, two if v[1].endswith('two_per_rb') else act, 32 if v[1] != 'all_pairs' else 8))
@@ -167,44 +167,53 @@ def default(args):
     env.close()
 
 
-def wall(args):
-    b, c, p, r = 1024, 25, 25, 25
-    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': LinearObsFunction}, num_envs=b,
-                    cue_actions='traffic')
-    env.reset(seed=1)
-    h = env.simulator.handle
-    acts = torch.randint(0, r * 21, (64, b, p), device=env.device, dtype=torch.int32)
-    variants = [(epw, fuse, blk, 0) for fuse in (1, 0) for epw in (0, 1, 2, 4) for blk in ((0, 512) if fuse else (0,))]
-    variants += [(0, 1, 0, 2), (2, 1, 0, 2), (0, 0, 0, 2)]           # member lists instead of the mask walk
-    if args.quick:
-        variants = [(0, 1, 0, 0), (0, 1, 0, 2), (0, 0, 0, 0), (0, 0, 0, 2)]
-    times = {v: [] for v in variants}
+def halves(args):
+    """BASELINE config 2 (1024 x 50, fused LinearObs) as ONE env of 1024 against TWO envs of 512 - on one stream, and on two streams
+    so that one half's 30 MB of stores can run under the other half's latency-bound step phase (the fused kernel
+    is launch 1.5 us + step phase 3.0 us + 8.9 us of stores, every workgroup in the same phase at the same time).  Wall time per
+    1024 env-steps, fresh actions, interleaved rounds, 2000 steps per sample."""
+    cfg = {'num_rbs': 25, 'num_cues': 25, 'num_due_pairs': 25, 'obs_fn': LinearObsFunction}
+    one = VecD2DEnv(dict(cfg), num_envs=1024, cue_actions='traffic'); one.reset(seed=1)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    same = [VecD2DEnv(dict(cfg), num_envs=512, cue_actions='traffic', first_env=512 * k) for k in range(2)]
+    for e in same:
+        e.reset(seed=1)
+    split = []
+    for k in range(2):
+        with torch.cuda.stream(streams[k]):
+            e = VecD2DEnv(dict(cfg), num_envs=512, cue_actions='traffic', first_env=512 * k); e.reset(seed=1); split.append(e)
+    torch.cuda.synchronize()
+    acts = torch.randint(0, 25 * 21, (64, 1024, 25), device=one.device, dtype=torch.int32)
+
+    def run(name, n):
+        for k in range(n):
+            a = acts[k % 64]
+            if name == 'one env of 1024':
+                one.step(a)
+            elif name == 'two envs of 512, one stream':
+                same[0].step(a[:512]); same[1].step(a[512:])
+            else:
+                for j in range(2):
+                    with torch.cuda.stream(streams[j]):
+                        split[j].step(a[512 * j:512 * (j + 1)])
+    names = ('one env of 1024', 'two envs of 512, one stream', 'two envs of 512, two streams')
+    times = {n: [] for n in names}
     for rnd in range(args.rounds):
-        for v in variants:
-            h.set_tuning(_native.TUNE_STEP_ENVS_PER_WG, v[0])
-            h.set_tuning(_native.TUNE_STEP_FUSE_OBS, v[1])
-            h.set_tuning(_native.TUNE_STEP_BLOCK, v[2])
-            h.set_tuning(_native.TUNE_STEP_WALK, v[3])
-            for k in range(20):
-                h.step(acts[k % 64].data_ptr())
-            torch.cuda.synchronize()
+        for n in names:
+            run(n, 200); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for k in range(500):
-                h.step(acts[k % 64].data_ptr())
-            torch.cuda.synchronize()
-            times[v].append((time.perf_counter() - t0) / 500 * 1e6)
-    for v in variants:
-        med = statistics.median(times[v])
-        emit({'sweep': 'default_wall_per_step', 'envs_per_wg': v[0], 'fuse_obs': v[1], 'block': v[2], 'walk': v[3],
-              'wall_us_per_step': round(med, 2), 'agent_steps_per_s': round(b * (c + p) / med * 1e6)}, args.out)
-    env.close()
+            run(n, 2000); torch.cuda.synchronize()
+            times[n].append((time.perf_counter() - t0) / 2000 * 1e6)
+    for n in names:
+        emit({'sweep': 'default_half_batches', 'variant': n, 'wall_us_per_1024_env_steps': round(statistics.median(times[n]), 2),
+              'min': round(min(times[n]), 2)}, args.out)
 
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['stress', 'default', 'wall', 'ablate', 'scale'])
+    ap.add_argument('what', choices=['stress', 'default', 'halves', 'ablate', 'scale'])
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--quick', action='store_true', help='stress: only the mask walk and the member lists')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
-    {'stress': stress, 'default': default, 'wall': wall, 'ablate': ablate, 'scale': scale}[a.what](a)
+    {'stress': stress, 'default': default, 'halves': halves, 'ablate': ablate, 'scale': scale}[a.what](a)

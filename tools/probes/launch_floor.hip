@@ -49,6 +49,11 @@ int main() {
         }
     }
     printf("1024 x 512 (persistent grid), lds 38912: %7.2f us\n", run<40>(1024, 512, 38 * 1024, out));
+    // round 5: the rollout kernel's shapes (15.4 KB of LDS per env; one or two links per thread) and a persistent grid of them
+    printf("4096 x 512, lds 15800, vgpr~48: %7.2f us\n", run<40>(4096, 512, 15800, out));
+    printf("4096 x 256, lds 15800, vgpr~48: %7.2f us\n", run<40>(4096, 256, 15800, out));
+    printf("4096 x 128, lds 15800, vgpr~48: %7.2f us\n", run<40>(4096, 128, 15800, out));
+    printf("2048 x 256 (persistent), lds 15800: %7.2f us\n", run<40>(2048, 256, 15800, out));
     printf("   1 x 64: %7.2f us\n", run<0>(1, 64, 0, out));
     return 0;
 }
