@@ -147,7 +147,10 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             }
         }
         pz[u] = pow10_tenth(pw) * in[u].rb_.x;
-        lds_put<f32x4>(L_LINK + my_off, f32x4{in[u].pos.x, in[u].pos.y, pz[u], __int_as_float(rb[u])});
+        // the tuple as two 8-byte halves (one ds_write2_b64): (x, y) goes out of the position row's own registers instead of being
+        // copied into a fresh four-register tuple first
+        lds_put<f32x2>(L_LINK + my_off, f32x2{in[u].pos.x, in[u].pos.y});
+        lds_put<f32x2>(L_LINK + my_off + 8u, f32x2{pz[u], __int_as_float(rb[u])});
         if (POWLAW) lds_put<f32x2>(L_EXPO + (my_off >> 1), f32x2{in[u].hh.x, in[u].hh.y});
         if (cfg_export_actions) { const unsigned oe = fresh((row + (unsigned)i) * 4u); RO_ST(at(a.rb_out, oe), rb[u]); RO_ST(at(a.pwr_out, oe), pw); }
         const unsigned slot = lds_atomic_inc(L_CNT + rbc * 4u);
@@ -218,6 +221,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
 
         // ---- pass 2: the RB's eight slots in one read, every slot a tuple address
         const unsigned rbc = oor[u] ? (unsigned)R : (unsigned)rb[u];
+        // (one ds_read_b128 + eight VALU to unpack it.  Eight ds_read_u16 off one address register instead - no VALU at all - were
+        // measured 9 % SLOWER, 19.65 -> 21.5 us: an LDS instruction costs this kernel about five VALU instructions,
+        // profiles/r5_ab_rollout_kernel.jsonl)
         const u32x4 mlist = lds_get<u32x4>(L_SLOTS + rbc * 16u);
         const unsigned off[RO_SLOTS] = {mlist.x & 0xFFFFu, mlist.x >> 16, mlist.y & 0xFFFFu, mlist.y >> 16,
                                         mlist.z & 0xFFFFu, mlist.z >> 16, mlist.w & 0xFFFFu, mlist.w >> 16};

@@ -56,6 +56,8 @@ def main():
     # differ in their bytes per link (file names of rounds 1-3: the table mode's summary is the --no-export one)
     suffix = ''
     key_obs = obs
+    if 'float64' in extra:
+        suffix += '_f64'; key_obs += '_f64'
     if '--reward-per-env' in extra:
         suffix += '_per_env_reward'; key_obs += '_per_env_reward'
     if obs != 'linear' and '--no-export' not in extra:
@@ -104,7 +106,7 @@ def main():
     out.write_text(json.dumps(rec, indent=1))
     if (wl, obs) == ('stress', 'table') and suffix == '':
         # the step kernel is 100 % of this mode's step: its own summary under the name VERDICT r1 asked for
-        step = {k: d for k, d in kernels.items() if 'step_kernel' in k}
+        step = {k: d for k, d in kernels.items() if 'step_kernel' in k or 'rollout_kernel' in k}
         for k, d in step.items():
             sq = d.get('sq_per_wave', {})
             d['summary'] = {'SQ_WAIT_ANY / SQ_WAVE_CYCLES': d.get('wait_any_fraction_of_wave_cycles'),
