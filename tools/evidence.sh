@@ -1,9 +1,10 @@
 #!/bin/bash
 # Regenerates the round's evidence on ONE GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 3000 -- 'bash tools/evidence.sh r5'
-# What it leaves: profiles/<tag>_kernel_stats_*.csv, profiles/<tag>_pmc_*.json (rocprofv3 kernel trace and PMC passes, collected
-# in SEPARATE runs, stamped with the digest of the kernel sources), profiles/<tag>_bench_lines.jsonl (the driver-like default
-# line and the stand-alone configurations), gpurun_out/<tag>_evidence/ (the GPU suite's log and everything raw).
+# What it leaves under gpurun_out/<tag>_evidence/ (the only directory gpurun brings back): profiles/<tag>_kernel_stats_*.csv,
+# profiles/<tag>_pmc_*.json (rocprofv3 kernel trace and PMC passes, collected in SEPARATE runs, stamped with the digest of the
+# kernel sources), profiles/<tag>_bench_lines.jsonl (the driver-like default line and the stand-alone configurations), the GPU
+# suite's log.  Then, here:  cp gpurun_out/<tag>_evidence/profiles/* profiles/
 tag=${1:-r5}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${tag}_evidence; mkdir -p $O; cd $R
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/tests.log 2>&1; echo "gpu tests rc=$? $(tail -1 $O/tests.log)" > $O/summary.txt
@@ -39,4 +40,5 @@ for l in lines:
     print(d['config']['workload'][:40], d['config'].get('obs_mode'), d.get('obs_dtype'), 'ms/step %.4f' % d['ms_per_step'], r['kernel'],
           'frac %.3f' % r['frac'], 'median frac', r.get('frac_at_median_launch'), 'traffic', r.get('traffic'))
 PY
-cat $O/summary.txt; ls profiles | grep "^${tag}_"
+mkdir -p $O/profiles; cp profiles/${tag}_kernel_stats_* profiles/${tag}_pmc_* profiles/${tag}_bench_lines.jsonl $O/profiles/
+cat $O/summary.txt; ls $O/profiles

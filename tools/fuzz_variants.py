@@ -55,6 +55,14 @@ def main():
             cfg['path_loss_model'] = Ple
         sim = Simulator(cfg)
         pos = random_layout(rng, b, cues, dues)
+        if rng.random() < 0.3 and cues + dues > 8:
+            # near / far geometry: some devices within 0.2 - 3 m of others, so that a receiver's same-RB terms span more than the
+            # rollout kernel's exactness window (its sorted / selection / sweep fallbacks run; csrc/d2d_rollout.hip)
+            d = pos.shape[1]
+            for _ in range(int(rng.integers(1, 12))):
+                e, i, j = int(rng.integers(0, b)), int(rng.integers(1, d)), int(rng.integers(1, d))
+                if i != j:
+                    pos[e, i] = pos[e, j] + (rng.uniform(0.2, 3.0) * np.array([np.cos(k := rng.uniform(0, 6.283)), np.sin(k)])).astype(np.float32)
         sim.set_positions(pos)
         sim.set_links(sim.default_link_keys())
         p = sim.config.num_pwr_actions
