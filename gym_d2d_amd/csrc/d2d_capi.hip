@@ -425,9 +425,10 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         return fail(D2D_ERR_UNSUPPORTED, "envs x links per GPU must stay below 2^32 / 24 (32-bit byte offsets in the step kernel)");
     s.reward_fn = h->reward_fn; s.reward_param = h->reward_param;
     s.write_table = h->obs_mode != D2D_OBS_NONE;
-    // nontemporal result stores: measured -0.7 ... -1.5 us in per-process A/Bs and +0.6 ... 0 us interleaved in one process
-    // (profiles/r3_ab_*): no consistent gain, so off unless asked for.  Never with LinearObs: the expansion kernel reads the
-    // table right behind this launch.
+    // nontemporal result stores: never with LinearObs (the expansion kernel reads the table right behind this launch).  In the
+    // generic kernels no consistent gain (profiles/r3_ab_*): off unless asked for.  The rollout kernel takes them by itself
+    // (below): interleaved in one process at 4096 x 512, obs-less 17.98 -> 17.51 us, compact table 25.11 -> 24.76
+    // (profiles/r5_rollout_nt_and_links_per_thread.jsonl)
     s.nt_results = h->tune_step_nt > 0 && h->obs_mode != D2D_OBS_LINEAR;
     s.rec_uniform = h->rec_uniform && h->tune_step_srec != 0;
     s.ablate = h->tune_step_ablate;
@@ -508,6 +509,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
             if (rlds.env_bytes <= 64 * 1024) {
                 s.rollout = 1; s.lds = rlds;
                 lpt = rl; tpe = N / rl; W = 0; s.lpt = lpt;
+                if (h->tune_step_nt < 0 && h->obs_mode != D2D_OBS_LINEAR) s.nt_results = 1;      // auto: on, see above
             }
         }
     }

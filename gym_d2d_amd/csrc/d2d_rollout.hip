@@ -412,9 +412,14 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     const int lane = tid & 63;
     // one DPP sum per GROUP OF 64 LINKS (LPT = 2: two per wave - links t.. and t + N/2..), each converted to fixed point on its own:
     // the float roundings are those of the one-link-per-thread kernels' wave sums, so the env's total has the same bits whatever LPT
+    // (beyond 1024 links the kernels this one must agree with carry two links per thread themselves and add a lane's two
+    // capacities before the wave sum: the same here - tools/fuzz_variants.py found the last-bit difference at 1536 links)
     unsigned long long fixed = 0ull;
+    if (LPT == 2 && N > 1024) fixed = to_fixed_32_32(wave_sum(caps[0] + caps[LPT - 1]));
+    else {
 #pragma unroll
-    for (int u = 0; u < LPT; ++u) fixed += to_fixed_32_32(wave_sum(caps[u]));
+        for (int u = 0; u < LPT; ++u) fixed += to_fixed_32_32(wave_sum(caps[u]));
+    }
     asm volatile("" ::"v"(pf));                                      // the prefetched words are consumed here (no instruction)
     // This wave's LDS atomics above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
     // above it in the instruction stream.  The last wave's reads below stay behind its own ticket (acquire).

@@ -494,3 +494,67 @@ def test_numpy_path_of_the_round4_options(native):
         assert nr.shape == (24,) and np.array_equal(tr.cpu().numpy(), nr) and np.array_equal(ts.cpu().numpy(), ns)
         assert ni['rb'] is None and ni['tx_pwr_dbm'] is None and np.array_equal(ti['capacity_mbps'].cpu().numpy(), ni['capacity_mbps'])
     t.close(); n.close()
+
+
+
+def test_link_pair_table_is_the_device_table_without_the_unused_entries(native):
+    """d2d_set_path_loss_link_table ([B,N,N] by (tx link, rx link): exactly the pairs the step reads) against
+    d2d_set_path_loss_table ([B,D,D] by device, everything else NaN): every output bit for bit, per-env and shared, a link list
+    in scrambled order; a new link list drops the table (D2D_ERR_STATE until a path-loss model is set again)."""
+    from gym_d2d_amd.simulator import Simulator
+    b, rbs, cues, dues = 5, 6, 7, 9
+    rng = np.random.default_rng(3)
+    sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b))
+    h = sim.handle
+    pos = random_layout(rng, b, cues, dues)
+    sim.set_positions(pos)
+    keys = sim.default_link_keys()
+    order = rng.permutation(len(keys))
+    sim.set_links([keys[k] for k in order])
+    n, d = len(keys), 1 + cues + 2 * dues
+    raw = np.concatenate([rng.integers(0, rbs * 24, (b, cues)), rng.integers(0, rbs * 21, (b, dues))], 1).astype(np.int32)[:, order]
+    p64 = pos.astype(np.float64)
+    dist = np.hypot(p64[:, :, None, 0] - p64[:, None, :, 0], p64[:, :, None, 1] - p64[:, None, :, 1])
+    with np.errstate(divide='ignore'):
+        full = 35.0 + 27.0 * np.log10(dist)                       # [B, D, D]; the diagonal is -inf and never read
+    h.set_obs_mode(native.OBS_TABLE)
+    for per_env in (True, False):
+        dev = full if per_env else full[0]
+        used = np.full_like(dev, np.nan)
+        used[..., sim.link_tx[:, None], sim.link_rx[None, :]] = dev[..., sim.link_tx[:, None], sim.link_rx[None, :]]
+        h.set_path_loss_table(used)
+        sim.step_arrays(raw)
+        a = _snapshot(sim, native)
+        h.set_path_loss_link_table(np.ascontiguousarray(dev[..., sim.link_tx[:, None], sim.link_rx[None, :]]))
+        sim.step_arrays(raw)
+        c = _snapshot(sim, native)
+        for buf in a:
+            assert np.array_equal(a[buf], c[buf], equal_nan=True), (per_env, buf)
+        assert np.isfinite(c['BUF_SINR_DB']).all()
+    with pytest.raises(native.NativeError):
+        h.set_path_loss_link_table(np.zeros((n + 1, n + 1)))       # not the length of the link list
+    h.set_links(sim.link_tx[:4], sim.link_rx[:4], sim.link_type[:4])   # a new list: the link-indexed table is gone with the old one
+    with pytest.raises(native.NativeError) as exc:
+        h.step()
+    assert exc.value.code == native.ERR_STATE
+    h.close()
+
+
+def test_profile_median_beside_the_mean(native):
+    """d2d_profile_median: the median launch duration of the events d2d_profile_enable brackets every launch with - what bench.py
+    quotes beside the mean, which a cold first launch pulls up."""
+    sim, pos, raw = _batch(64, 16, 32, 32, rng_seed=5)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_LINEAR)
+    h.set_tuning(native.TUNE_STEP_FUSE_OBS, 0)                      # two kernels per step: both are timed
+    h.profile_reset(); h.profile_enable(True)
+    for _ in range(25):
+        sim.step_arrays(raw)
+    for kernel in (0, 1):
+        total, launches = h.profile_read(kernel)
+        med = h.profile_median(kernel)
+        assert launches == 25 and 0.0 < med <= 1.5 * total / launches, (kernel, total, launches, med)
+    h.profile_enable(False)
+    h.profile_reset()
+    assert h.profile_median(0) == 0.0
+    h.close()

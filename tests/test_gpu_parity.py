@@ -359,8 +359,8 @@ def test_shadowing_path_loss(native):
 
 
 def test_custom_python_path_loss_with_a_batch(native):
-    """The Python-plugin route for B > 1: the user's PathLoss is evaluated per env into a [B, D, D] table
-    (d2d_set_path_loss_table, per_env = 1) after every position change."""
+    """The Python-plugin route for B > 1: the user's PathLoss is evaluated per env for the (transmitter of a link) x (receiver of
+    a link) pairs into a [B, N, N] table by link pair (d2d_set_path_loss_link_table, per_env = 1) after every position change."""
     import math
     from gym_d2d_amd.path_loss import PathLoss
     from gym_d2d_amd.simulator import Simulator
