@@ -28,10 +28,10 @@
 //     word requested before the current one's members are consumed.  Beyond 1024 links per env (the summary word's reach)
 //     per-RB member lists take over (slot counter + eight u16 slots per RB, sorted in registers by the receiver).  A masked
 //     all-pairs sweep is the fallback (rb outside [0,R), nothing fits in LDS, a list overflows where no masks exist).  All
-//     of them visit interferers in ascending link index through the same fmaf, hence produce identical bits.  (Round 4: the
-//     lists are also what the rollout kernel uses in the obs-less mode, where instructions, not stores, pace the step.)  Measured
-//     and rejected, with the evidence under profiles/: a stable counting sort by RB (r2: 40.0 vs 35.3 us), a flattened
-//     walk, the member lists in the rollout kernel (r3: 31.7 vs 30.8 us - the walk is not what paces the kernel);
+//     of them visit interferers in ascending link index through the same fmaf, hence produce identical bits.  (Round 5: where
+//     RBs are sparsely occupied - N <= 4 R - the rollout configuration has a kernel of its own built on the lists,
+//     csrc/d2d_rollout.hip; this file's HOT level 1 is the rollout configuration with the MASKS, for dense occupancy.)
+//     Measured and rejected, evidence under profiles/ (NEGATIVE_RESULTS.md): a stable counting sort by RB, a flattened walk;
 //   * what paces the kernel is the memory pipeline: bytes and vector-memory requests (dropping the optional decoded
 //     (rb, pwr) planes: -2.3 us; record rows by scalar loads: -2 us; one more prefetch load per lane: +1 us), not LDS
 //     latency chains, store-instruction counts or the walk's imbalance (profiles/r3_ab_*.jsonl);
