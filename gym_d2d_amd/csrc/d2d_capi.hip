@@ -82,6 +82,7 @@ struct d2d_handle {
     bool lpos_dirty = true;
     unsigned long long* dbg = nullptr;   // diagnostic builds only
     bool rec_uniform = false;       // records identical within every aligned group of 64 links (refresh_tables)
+    bool rec_uniform128 = false;    // ... and within every aligned group of 128: the rollout kernel's two links per thread
     bool std_layout = false;        // link i < C is (cue i -> mbs), link C + k is (due 2k -> due 2k+1): d2d_reset_positions writes lpos itself
     float* gain_table = nullptr;
     size_t gain_elems = 0;
@@ -280,6 +281,17 @@ int refresh_tables(d2d_handle* h) {
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->rec_uniform = uniform;
+    bool uniform128 = uniform && N % 128 == 0;
+    for (int g = 0; g + 1 < N / 64 && uniform128; g += 2) {
+        const int i = g * 64, j = i + 64;
+        uint32_t pi, pj;
+        std::memcpy(&pi, &rc[4 * i + 3], 4); std::memcpy(&pj, &rc[4 * j + 3], 4);
+        uniform128 = (ra[4 * i] >> D2D_REC_TYPE_SHIFT) == (ra[4 * j] >> D2D_REC_TYPE_SHIFT) && ra[4 * i + 2] == ra[4 * j + 2] &&
+                     ra[4 * i + 3] == ra[4 * j + 3] && std::memcmp(&rb[4 * i], &rb[4 * j], 16) == 0 &&
+                     std::memcmp(&rc[4 * i], &rc[4 * j], 12) == 0 && (pi & 0xFFFFu) == (pj & 0xFFFFu) &&
+                     rech[2 * i] == rech[2 * j] && rech[2 * i + 1] == rech[2 * j + 1];
+    }
+    h->rec_uniform128 = uniform128;
     h->tables_dirty = false;
     h->lpos_dirty = true;                       // the link -> device map may have changed
     return D2D_OK;
@@ -451,7 +463,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     const bool rollout_cfg = action_mode == 0 && h->n_fixed == 0 && h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY && h->bucketing &&
                              !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && h->tune_step_ablate == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
-                             N % 64 == 0 && N <= 2048;
+                             N % 64 == 0 && N <= 1024;
     const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE || rollout_cfg);
     s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (lists_pay ? 2 : 0);
 
@@ -495,15 +507,20 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.lpt = lpt;
     d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, &s.lds);
     // The rollout kernel (d2d_rollout.hip): raw agent actions for every link, SystemCapacity, one env per workgroup, a power-law
-    // path loss, member lists wanted - one link per thread, or two (N / 2 threads per env: every per-wave instruction paid once
-    // per 128 links) when N is a multiple of 128.  Its own LDS layout: no masks, 15 KB per env at 512 links on 256 RBs.
+    // path loss, member lists wanted.  Its own LDS layout: no masks, 17 KB per env at 512 links on 256 RBs.
     if (lists && s.walk == 2 && rollout_cfg && h->col_mode == 0) {
-        // one link per thread, or two (N / 2 threads per env: every per-wave instruction paid once per 128 links, half the waves to
-        // launch) - measured: two win in the obs-less mode (19.3 vs 19.9 us), one where the table is written (25.8 vs 26.3); two
-        // only with scalar records (per-lane records for two links push the kernel past 64 VGPRs)
-        int rl = h->tune_step_lpt > 0 ? h->tune_step_lpt : (N % 128 == 0 && s.rec_uniform && h->obs_mode == D2D_OBS_NONE ? 2 : 1);
-        if ((rl == 2 && N % 128 != 0) || N / rl > 1024) rl = N <= 1024 ? 1 : 2;
-        if (N % (64 * rl) == 0 && N / rl <= 1024) {
+        // One link per thread, or two ADJACENT ones (links 2t and 2t + 1, N / 2 threads per env): every per-wave instruction - the
+        // scalar record load, barriers, ballots, the wave reduction, the ticket - is paid once per 128 links, half as many waves are
+        // launched, and a thread's two results are one 8-byte element of every plane and 48 contiguous bytes of the table.  Two
+        // wherever the device classes fill aligned groups of 128 links (one scalar record load serves the wave; per-lane records
+        // for two links push the kernel past 64 VGPRs).  Same box, 4096 x 512: obs-less 20.2 -> 19.0 us, compact table 26.7 -> 24.5
+        // (profiles/r5_table_rows_through_lds.jsonl).
+        // (Other exponents - the power-law kernel, twice the arithmetic per pair - gain nothing from two: COST-Hata obs-less 32.0 us
+        // with one link per thread, 33.4 with two; table 37.3 / 37.8.)
+        int rl = h->tune_step_lpt > 0 ? h->tune_step_lpt : (h->rec_uniform128 && s.rec_uniform && h->mode == d2d::PL_INV_SQUARE ? 2 : 1);
+        if (rl != 2 || N % 128 != 0) rl = 1;
+        if (rl == 2 && !h->rec_uniform128) s.rec_uniform = false;     // forced by the tuning key on other records: per-lane records
+        {
             d2d::StepLds rlds;
             d2d::rollout_lds_layout(N, s.R, (int)h->mode, &rlds);
             if (rlds.env_bytes <= 64 * 1024) {

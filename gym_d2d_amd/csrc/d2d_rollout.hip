@@ -23,8 +23,13 @@
 //     hence independent of the order and equal - bit for bit - to the ascending-order sum of the mask walk and the
 //     all-pairs sweep.  The two extremes are tracked with one v_max3 / v_min3 pair per two terms; a lane outside the
 //     window (1e-6 of lanes without, 5e-5 with the own term at BASELINE config 3 geometry) re-does its sum in sorted order;
-//   * LPT = 2: a thread carries two links (t and t + N / 2), so every per-WAVE instruction - scalar loads, barriers, ballots,
-//     the wave reduction, the ticket - is paid once per 128 links instead of once per 64, and half as many waves are launched.
+//   * LPT = 2: a thread carries two ADJACENT links (2t and 2t + 1), so every per-WAVE instruction - the scalar record load, barriers,
+//     ballots, the wave reduction, the ticket - is paid once per 128 links instead of once per 64, half as many waves are launched,
+//     the thread's two actions are one 8-byte load and its two results one 8-byte element of every plane.  The capacity sum
+//     keeps the bits of the one-link kernels: their wave sum is a balanced tree over adjacent links, whose first level here is the
+//     lane's own pair (wave_sum_halves);
+//   * with two links per thread the TABLE ROWS (24 bytes per link) leave through LDS, so that every store instruction writes
+//     1024 contiguous bytes (see the results section: 26.7 -> 24.5 us in the table mode).
 // Same arithmetic as step_kernel everywhere else (tests/test_gpu_step_variants.py holds the two bit-identical).
 //
 // Worst case: an env whose actions pile more than eight links on one RB costs its members a scan of the pool (<= N entries);
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     constexpr bool POWLAW = MODE == PL_POWER;
     static_assert(MODE == PL_INV_SQUARE || MODE == PL_POWER, "the rollout kernel serves the power laws");
     static_assert(LPT == 1 || LPT == 2, "one or two links per thread");
-    const int N = a.N, R = a.R, TPE = a.tpe;                     // N == LPT * TPE == LPT * blockDim.x
+    const int N = a.N, R = a.R, TPE = a.tpe;                     // N == LPT * TPE == LPT * blockDim.x; thread t: links LPT * t + u
     const int tid = threadIdx.x, b = (int)blockIdx.x;
     const unsigned row = (unsigned)b * (unsigned)N;              // element offsets fit 32 bits (run_step refuses B * N * 24 >= 2^32)
     const bool cfg_export_actions = a.rb_out != nullptr;
@@ -80,14 +85,21 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
 
     // ---- prologue: the links' loads, issued before any LDS work or barrier (their latency overlaps pass 0)
     LinkRaw in[LPT];
+    if (SREC && LPT == 2) {                                      // the thread's two actions: adjacent columns, one 8-byte load
+        const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, fresh((row + 2u * (unsigned)tid) * 4u)));
+        in[0].act0 = aa.x; in[LPT - 1].act0 = aa.y;
+    }
+    // the records of a wave's 64 * LPT links are identical (StepArgs::rec_uniform; the host offers two links per thread only
+    // where that holds for aligned groups of 128): the whole record in ONE 64-byte scalar load per wave.  rec_grp holds a 64-byte
+    // row per group of 64 links, so the wave's first link index is the byte offset of its row.
+    i32x16 g;
+    if (SREC) g = scalar_load64(reinterpret_cast<const unsigned char*>(a.rec_grp) + (unsigned)(__builtin_amdgcn_readfirstlane(tid) * LPT));
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
-        const int i = tid + u * TPE;
+        const int i = LPT * tid + u;
         if (SREC) {
-            // the records of a wave's 64 links are identical (StepArgs::rec_uniform): the whole record in one 64-byte scalar load
-            in[u].act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
+            if (LPT == 1) in[u].act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
             in[u].act1 = 0;
-            const i32x16 g = scalar_load64(reinterpret_cast<const unsigned char*>(a.rec_grp) + (unsigned)(__builtin_amdgcn_readfirstlane(tid) + u * TPE));
             in[u].ra = make_int4(g[2], 0, g[0], g[1]);
             in[u].rb_ = make_float4(__int_as_float(g[4]), __int_as_float(g[5]), __int_as_float(g[6]), __int_as_float(g[7]));
             in[u].rc = make_float4(__int_as_float(g[8]), __int_as_float(g[9]), __int_as_float(g[10]), __int_as_float(g[11]));
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             for (int k = tid + 2 * TPE; k < nl; k += TPE) { const unsigned f = k < rows ? e2 : 0u; lds_put<u32x4>(L_SLOTS + (unsigned)k * 16u, u32x4{f, f, f, f}); }
         }
         if (tid == TPE - 1) {
-            lds_put<f32x4>(L_LINK + EMPTY, f32x4{1.0e18f, 1.0e18f, 0.0f, __int_as_float(-1)});
+            lds_put<f32x4>(L_LINK + EMPTY, f32x4{1.0e18f, 1.0e18f, -0.0f, __int_as_float(-1)});
             if (POWLAW) lds_put<f32x2>(L_EXPO + (EMPTY >> 1), f32x2{-1.0f, 0.0f});
         }
         if (tid < 5) lds_put<u32x4>((unsigned)tid * 16u, u32x4{0u, 0u, 0u, 0u});          // sum, dump, flags[4]: 80 bytes
@@ -124,12 +136,13 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- pass 1: decode, stage the transmitter tuple, enter the RB's list
-    int rb[LPT];
+    int rb[LPT], pwr[LPT];
     float pz[LPT];                                               // effective tx power (mW), the tuple's third component
     bool oor[LPT];
+    unsigned slot[LPT], row_off[LPT];
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
-        const int i = tid + u * TPE;
+        const int i = LPT * tid + u;
         const unsigned my_off = (unsigned)i << 4;
         const unsigned P = __float_as_uint(in[u].rc.w) & 0xFFFFu;
         // the host keeps the bound below R * P (refresh_tables): an action inside it decodes to rb < R by one multiply-high
@@ -152,16 +165,29 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         lds_put<f32x2>(L_LINK + my_off, f32x2{in[u].pos.x, in[u].pos.y});
         lds_put<f32x2>(L_LINK + my_off + 8u, f32x2{pz[u], __int_as_float(rb[u])});
         if (POWLAW) lds_put<f32x2>(L_EXPO + (my_off >> 1), f32x2{in[u].hh.x, in[u].hh.y});
-        if (cfg_export_actions) { const unsigned oe = fresh((row + (unsigned)i) * 4u); RO_ST(at(a.rb_out, oe), rb[u]); RO_ST(at(a.pwr_out, oe), pw); }
-        const unsigned slot = lds_atomic_inc(L_CNT + rbc * 4u);
-        const bool ovf = slot >= (unsigned)RO_SLOTS;
-        lds_put<unsigned short>(ovf ? L_DUMP : L_SLOTS + rbc * 16u + slot * 2u, (unsigned short)my_off);
+        pwr[u] = pw;
+        row_off[u] = L_SLOTS + rbc * 16u;
+        slot[u] = lds_atomic_inc(L_CNT + rbc * 4u);
+    }
+    // (the slot numbers of the thread's links come back together: one LDS round trip, not one per link)
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+        const int i = LPT * tid + u;
+        const bool ovf = slot[u] >= (unsigned)RO_SLOTS;
+        lds_put<unsigned short>(ovf ? L_DUMP : row_off[u] + slot[u] * 2u, (unsigned short)((unsigned)i << 4));
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(ovf) != 0ull)) {
             if (ovf) {                                           // the ninth and later links of an RB: the env's overflow pool
                 const unsigned ps = lds_atomic_inc(L_FLAGS + 12u);
                 lds_put<u32x2>(L_POOL + ps * 8u, u32x2{(unsigned)rb[u], (unsigned)i});
             }
         }
+    }
+    if (cfg_export_actions) {                                    // the decoded planes: the thread's LPT adjacent elements in one store
+        const unsigned oe = fresh((row + (unsigned)(LPT * tid)) * 4u);
+        if (LPT == 2) {
+            RO_ST(reinterpret_cast<i32x2*>(at(a.rb_out, oe)), (i32x2{rb[0], rb[LPT - 1]}));
+            RO_ST(reinterpret_cast<i32x2*>(at(a.pwr_out, oe)), (i32x2{pwr[0], pwr[LPT - 1]}));
+        } else { RO_ST(at(a.rb_out, oe), rb[0]); RO_ST(at(a.pwr_out, oe), pwr[0]); }
     }
     __syncthreads();
 
@@ -170,14 +196,15 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     {
         const int bq = b + a.prefetch_envs;
         const int bp = bq < a.B ? bq : a.B - 1;
-#pragma unroll
-        for (int u = 0; u < LPT; ++u) pf ^= *at(a.actions, fresh(((unsigned)bp * (unsigned)N + (unsigned)(tid + u * TPE)) * 4u));
+        const unsigned op = fresh(((unsigned)bp * (unsigned)N + (unsigned)(LPT * tid)) * 4u);
+        if (LPT == 2) { const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, op)); pf = aa.x ^ aa.y; }
+        else pf = *at(a.actions, op);
     }
 
-    float caps[LPT];
+    float caps[LPT], rates[LPT], sinrs[LPT], snrs[LPT];
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
-        const int i = tid + u * TPE;
+        const int i = LPT * tid + u;
         const unsigned my_off = (unsigned)i << 4;
         const int type = (in[u].ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const float2 rx = make_float2(in[u].pos.z, in[u].pos.w);
@@ -231,7 +258,12 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // its term (pz * g_own - the very product the slot's evaluation repeats, same operands, same rounding)
         const f32x2 rxv = {rx.x, rx.y};
         double acc = -(double)(pz[u] * g_own);
-        unsigned tmax = 0u, tmin = 0xFFFFFFFFu;
+        // The empty slots' stand-in has power -0.0: its term, -0.0, leaves the sum alone and its bits, 0x80000000, are neutral
+        // for BOTH extremes - below every real term as a signed integer (the maximum), above every one as an unsigned (the
+        // minimum) - so no instruction is spent on telling empty slots from members.  (A real term of +0.0 - zero power, or an
+        // underflow - makes the minimum 0 and sends the lane to the sorted sum: conservative.)
+        int tmax = 0;
+        unsigned tmin = 0xFFFFFFFFu;
 #define RO_PAIR(k, o)                                                                                                   \
         {                                                                                                               \
             const f32x2 dd = f32x2{(o).x, (o).y} - rxv;               /* one v_pk_add_f32: (x, y) sit in adjacent registers */ \
@@ -240,9 +272,23 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             if (POWLAW) dmin = min(dmin, __float_as_int(d2));                                                           \
             const float t = (o).z * g;                               /* simulator.py:97-101, linear mW */               \
             acc += (double)t;                                                                                           \
-            tmax = max(tmax, __float_as_uint(t)); tmin = min(tmin, __float_as_uint(t) - 1u);   /* zero terms: ignored */ \
+            tmax = max(tmax, __float_as_int(t)); tmin = min(tmin, __float_as_uint(t));                                  \
         }
-        {
+        if (POWLAW) {
+            // (the power law's pairs carry an exponent pair each and a longer evaluation: three and three in flight - six take the
+            // two-link kernel to 73 VGPRs = 6 waves per SIMD, and measured slower with one link too: COST-Hata obs-less 33.9 -> 32.0 us)
+            {
+                const f32x4 o0 = lds_get<f32x4>(L_LINK + off[0]), o1 = lds_get<f32x4>(L_LINK + off[1]), o2 = lds_get<f32x4>(L_LINK + off[2]);
+                RO_PAIR(0, o0) RO_PAIR(1, o1) RO_PAIR(2, o2)
+                asm volatile("" ::"v"(o0.w), "v"(o1.w), "v"(o2.w));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const f32x4 o3 = lds_get<f32x4>(L_LINK + off[3]), o4 = lds_get<f32x4>(L_LINK + off[4]), o5 = lds_get<f32x4>(L_LINK + off[5]);
+                RO_PAIR(3, o3) RO_PAIR(4, o4) RO_PAIR(5, o5)
+                asm volatile("" ::"v"(o3.w), "v"(o4.w), "v"(o5.w));
+            }
+        } else {
             const f32x4 o0 = lds_get<f32x4>(L_LINK + off[0]), o1 = lds_get<f32x4>(L_LINK + off[1]), o2 = lds_get<f32x4>(L_LINK + off[2]),
                         o3 = lds_get<f32x4>(L_LINK + off[3]), o4 = lds_get<f32x4>(L_LINK + off[4]), o5 = lds_get<f32x4>(L_LINK + off[5]);
             RO_PAIR(0, o0) RO_PAIR(1, o1) RO_PAIR(2, o2) RO_PAIR(3, o3) RO_PAIR(4, o4) RO_PAIR(5, o5)
@@ -259,7 +305,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
 #undef RO_PAIR
         // all partial sums exact <=> the sum is the ascending-order sum: largest and smallest non-zero term within 2^25
         // (nine values of 24 bits inside the 53 of a double); compared on the raw bits (conservative by less than one binade)
-        const bool inexact = tmax - tmin >= (25u << 23);
+        const bool inexact = (unsigned)tmax - tmin >= (25u << 23);
         const bool big = members > (unsigned)RO_SLOTS;           // more members than the row holds: the rest is in the pool
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(inexact | big | oor[u]) != 0ull)) {
             if (oor[u]) {
@@ -341,27 +387,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         const bool ok = sinr_db > sens;                              // simulator.py:123,149
         const float rate = ok ? sh : 0.0f;
         const float cap = ok ? bw_mhz * sh : 0.0f;                   // simulator.py:150-151
-        {
-            const unsigned o4 = fresh((row + (unsigned)i) * 4u);
-            RO_ST(at(a.sinr_db, o4), sinr_db);
-            RO_ST(at(a.snr_db, o4), snr_db);
-            RO_ST(at(a.rate, o4), rate);
-            RO_ST(at(a.cap, o4), cap);
-        }
-        if (a.write_table) {                                         // obs_fn.py:57-60
-            const unsigned o4t = fresh((row + (unsigned)i) * 4u);
-            float2* t = reinterpret_cast<float2*>(at(a.table, (o4t << 2) + (o4t << 1)));
-            if (NT) {
-                f32x2* tv = reinterpret_cast<f32x2*>(t);
-                const f32x2 v0 = {in[u].pos.x, in[u].pos.y}, v1 = {rx.x, rx.y}, v2 = {sinr_db, snr_db};
-                __builtin_nontemporal_store(v0, tv); __builtin_nontemporal_store(v1, tv + 1); __builtin_nontemporal_store(v2, tv + 2);
-            } else {
-                t[0] = make_float2(in[u].pos.x, in[u].pos.y);
-                t[1] = rx;
-                t[2] = make_float2(sinr_db, snr_db);
-            }
-        }
-        caps[u] = cap;
+        caps[u] = cap; rates[u] = rate; sinrs[u] = sinr_db; snrs[u] = snr_db;
 
         // per-lane rarities behind ONE wave-uniform branch: SystemCapacity's -1 rule (reward_fn.py:29-41: I am a non-D2D link whose
         // capacity is <= min_capacity and some D2D link shares my RB), a non-finite SINR / zero distance, a capacity too large for
@@ -407,19 +433,68 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         }
     }
 
+    // ---- results: the thread's LPT links are adjacent elements of every plane and adjacent rows of the table
+    {
+        const unsigned o4 = fresh((row + (unsigned)(LPT * tid)) * 4u);
+        if (LPT == 2) {
+            RO_ST(reinterpret_cast<f32x2*>(at(a.sinr_db, o4)), (f32x2{sinrs[0], sinrs[LPT - 1]}));
+            RO_ST(reinterpret_cast<f32x2*>(at(a.snr_db, o4)), (f32x2{snrs[0], snrs[LPT - 1]}));
+            RO_ST(reinterpret_cast<f32x2*>(at(a.rate, o4)), (f32x2{rates[0], rates[LPT - 1]}));
+            RO_ST(reinterpret_cast<f32x2*>(at(a.cap, o4)), (f32x2{caps[0], caps[LPT - 1]}));
+        } else {
+            RO_ST(at(a.sinr_db, o4), sinrs[0]);
+            RO_ST(at(a.snr_db, o4), snrs[0]);
+            RO_ST(at(a.rate, o4), rates[0]);
+            RO_ST(at(a.cap, o4), caps[0]);
+        }
+        if (a.write_table) {                                         // obs_fn.py:57-60: (tx, rx, sinr, snr) per link, 24 bytes
+            const unsigned o4t = fresh((row + (unsigned)(LPT * tid)) * 4u);
+            unsigned char* t = reinterpret_cast<unsigned char*>(at(a.table, (o4t << 2) + (o4t << 1)));
+            if (LPT == 2) {                                          // 48 contiguous bytes
+                const float4 p0 = in[0].pos, p1 = in[LPT - 1].pos;
+                const f32x4 v0 = {p0.x, p0.y, p0.z, p0.w}, v1 = {sinrs[0], snrs[0], p1.x, p1.y}, v2 = {p1.z, p1.w, sinrs[LPT - 1], snrs[LPT - 1]};
+                if (a.lds.env_bytes - LDS_HEAD_BYTES >= (unsigned)N * 24u) {
+                    // Through LDS, so that every store instruction writes 1024 CONTIGUOUS bytes: a lane's own 48 bytes, stored
+                    // directly, leave every 128-byte line to be completed by three instructions - fine for L2 when it merges them
+                    // (28.9 us), ruinous with the nt hint (37 us: partial lines go out as they are), and either way behind full
+                    // lines (24.3 us; 26.7 with one link per thread.  profiles/r5_table_rows_through_lds.jsonl).  The staging area is
+                    // the tuples and lists themselves, which nobody reads after this barrier: the wave's 128 rows at their place in
+                    // the env's table image, written and read back by the same wave (no second barrier).
+                    __syncthreads();
+                    const unsigned mine = LDS_HEAD_BYTES + (unsigned)tid * 48u;
+                    const unsigned wave0 = LDS_HEAD_BYTES + (unsigned)(tid & ~63) * 48u + (unsigned)(tid & 63) * 16u;
+                    lds_put<f32x4>(mine, v0); lds_put<f32x4>(mine + 16u, v1); lds_put<f32x4>(mine + 32u, v2);
+                    const f32x4 w0 = lds_get<f32x4>(wave0), w1 = lds_get<f32x4>(wave0 + 1024u), w2 = lds_get<f32x4>(wave0 + 2048u);
+                    const unsigned o4w = fresh((row + (unsigned)(LPT * (tid & ~63))) * 4u);
+                    unsigned char* tw = reinterpret_cast<unsigned char*>(at(a.table, (o4w << 2) + (o4w << 1))) + (unsigned)(tid & 63) * 16u;
+                    RO_ST(reinterpret_cast<f32x4*>(tw), w0);
+                    RO_ST(reinterpret_cast<f32x4*>(tw + 1024), w1);
+                    RO_ST(reinterpret_cast<f32x4*>(tw + 2048), w2);
+                } else {                                             // (an env whose LDS is smaller than its table: R < N / 4.  Never nt)
+                    *reinterpret_cast<f32x4*>(t) = v0; *reinterpret_cast<f32x4*>(t + 16) = v1; *reinterpret_cast<f32x4*>(t + 32) = v2;
+                }
+            } else {
+                const float4 p0 = in[0].pos;
+                RO_ST(reinterpret_cast<f32x2*>(t), (f32x2{p0.x, p0.y}));
+                RO_ST(reinterpret_cast<f32x2*>(t + 8), (f32x2{p0.z, p0.w}));
+                RO_ST(reinterpret_cast<f32x2*>(t + 16), (f32x2{sinrs[0], snrs[0]}));
+            }
+        }
+    }
+
     // ---- reward: barrier-free ticket reduction (see step_kernel): DPP wave sum, 32.32 fixed-point capacity total in LDS (the
     // 64-bit integer sum does not depend on arrival order), the wave that draws the last ticket finishes the env
     const int lane = tid & 63;
-    // one DPP sum per GROUP OF 64 LINKS (LPT = 2: two per wave - links t.. and t + N/2..), each converted to fixed point on its own:
-    // the float roundings are those of the one-link-per-thread kernels' wave sums, so the env's total has the same bits whatever LPT
-    // (beyond 1024 links the kernels this one must agree with carry two links per thread themselves and add a lane's two
-    // capacities before the wave sum: the same here - tools/fuzz_variants.py found the last-bit difference at 1536 links)
-    unsigned long long fixed = 0ull;
-    if (LPT == 2 && N > 1024) fixed = to_fixed_32_32(wave_sum(caps[0] + caps[LPT - 1]));
-    else {
-#pragma unroll
-        for (int u = 0; u < LPT; ++u) fixed += to_fixed_32_32(wave_sum(caps[u]));
-    }
+    // one sum per GROUP OF 64 LINKS, each converted to fixed point on its own, with the roundings of the one-link-per-thread
+    // kernels' wave sum - a balanced tree over adjacent links: pairs, fours, ... 32 + 32.  LPT = 2: a lane's two links ARE
+    // the first level, the DPP steps the next four, and the two halves of the wave end as the two groups' sums (wave_sum_halves)
+    // - so the env's total has the same bits whatever LPT
+    unsigned long long fixed;
+    if (LPT == 2) {
+        float lo, hi;
+        wave_sum_halves(caps[0] + caps[LPT - 1], lo, hi);
+        fixed = to_fixed_32_32(lo) + to_fixed_32_32(hi);
+    } else fixed = to_fixed_32_32(wave_sum(caps[0]));
     asm volatile("" ::"v"(pf));                                      // the prefetched words are consumed here (no instruction)
     // This wave's LDS atomics above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
     // above it in the instruction stream.  The last wave's reads below stay behind its own ticket (acquire).

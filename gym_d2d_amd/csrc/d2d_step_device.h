@@ -38,6 +38,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// The sums of the wave's lower and upper 32 lanes, each by the tree wave_sum builds over 32 lanes (its first five levels): what
+// a kernel with two ADJACENT links per lane needs to reproduce wave_sum over 64 links - the lane's own pair is level one.
+__device__ __forceinline__ void wave_sum_halves(float v, float& lo, float& hi) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // v * 2^32 truncated to an integer, for 0 <= v < 2^32: whole part and fraction converted separately (two v_cvt_u32_f32)
 // instead of the generic float -> u64 sequence; the same value (the scaling by 2^32 is exact).
 __device__ __forceinline__ unsigned long long to_fixed_32_32(float v) {

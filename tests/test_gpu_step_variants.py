@@ -515,8 +515,9 @@ def test_rollout_kernel_serves_the_obs_less_mode(native):
     assert tuple(outs[-1][0]['rew'].shape) == (B,)
 
 
+@pytest.mark.parametrize('shape', [(32, 64, 64), (64, 128, 128)], ids=['classes_of_64', 'classes_of_128'])
 @pytest.mark.parametrize('lpt', [1, 2])
-def test_rollout_kernel_rare_paths_are_bit_identical(native, lpt):
+def test_rollout_kernel_rare_paths_are_bit_identical(native, lpt, shape):
     """csrc/d2d_rollout.hip keeps every per-lane rarity behind ballot branches the common wave never enters; this drives each of
     them on purpose and holds the result to the mask walk and the all-pairs sweep, bit for bit:
       env 0  three links on one RB, one interferer 0.3 m from a receiver, another 480 m away at 0 dBm: the lane's terms span more
@@ -524,8 +525,11 @@ def test_rollout_kernel_rare_paths_are_bit_identical(native, lpt):
       env 1  twelve links on one RB (four of them in the overflow pool) with the same near / far pair -> selection in ascending order;
       env 2  forty links on one RB with the pair -> more than 32 members and inexact -> the all-pairs sweep;
       env 3  two links on the same OUT-OF-RANGE RB (they interfere with each other, d2d_env.py:94-96) and a negative action;
-      env 4  nine links on one RB, ordinary geometry: the pool, order-free and exact."""
-    b, rbs, cues, dues = 12, 32, 64, 64
+      env 4  nine links on one RB, ordinary geometry: the pool, order-free and exact.
+    Two links per thread (adjacent links 2t, 2t + 1) read the 128 records of a wave with one scalar load where the device
+    classes fill aligned groups of 128 links (128 + 128), and per lane where they do not (64 + 64)."""
+    rbs, cues, dues = shape
+    b = 12
     sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=77)
     h = sim.handle
     n = cues + dues

@@ -39,7 +39,7 @@ def prepare(names):
         print('built', out.name)
 
 
-def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1):
+def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1, path_loss='log2'):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools'))
     from gym_d2d_amd import _native
     _native.LIB_PATH = Path(lib).resolve()
@@ -54,12 +54,16 @@ def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1):
     from ab_step import timed
     from gym_d2d_amd.envs import VecD2DEnv
     from gym_d2d_amd.envs.obs_fn import LinearObsFunction, OwnLinkObsFunction, SignalPlanesObsFunction
+    extra = {}
+    if path_loss == 'cost_hata':                 # an exponent other than 2: the power-law kernels
+        from gym_d2d_amd.path_loss import CostHataPathLoss
+        extra = {'path_loss_model': CostHataPathLoss}
     if workload == 'stress':
         b, c, p, r = 4096, 256, 256, 256
         if mode == 'none':           # the learner configuration: no table, SystemCapacity's scalar once per env
-            env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': SignalPlanesObsFunction}, num_envs=b, reward_per_env=True)
+            env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': SignalPlanesObsFunction, **extra}, num_envs=b, reward_per_env=True)
         else:
-            env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
+            env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction, **extra}, num_envs=b)
         cols = c + p
     else:
         b, c, p, r = 1024, 25, 25, 25
@@ -74,13 +78,13 @@ def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1):
         h.set_tuning(_native.TUNE_STEP_LPT, lpt)
     act = torch.randint(0, r * 21, (64, b, cols), device=env.device, dtype=torch.int32)
     t = [timed(h, act, 32) for _ in range(15)]
-    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'obs': mode, 'walk': walk, 'lpt': lpt, 'export_rb_pwr': int(export), 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
+    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'path_loss': path_loss, 'obs': mode, 'walk': walk, 'lpt': lpt, 'export_rb_pwr': int(export), 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
 
 
-def run(workload, passes, export=True, mode='table', walk=-1, lpt=-1):
+def run(workload, passes, export=True, mode='table', walk=-1, lpt=-1, path_loss='log2'):
     for k in range(passes):
         for lib in sorted(LIBS.glob('*.so')):
-            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload, '--mode', mode, '--walk', str(walk), '--lpt', str(lpt)] + ([] if export else ['--no-export']),
+            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload, '--mode', mode, '--walk', str(walk), '--lpt', str(lpt), '--path-loss', path_loss] + ([] if export else ['--no-export']),
                                capture_output=True, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             print(line[-1] if line else f'{lib.name}: failed {r.stderr[-300:]}', flush=True)
@@ -95,11 +99,12 @@ if __name__ == '__main__':
     ap.add_argument('--mode', default='table', choices=['table', 'none'], help='stress: compact table (OwnLinkObs) or the obs-less learner mode')
     ap.add_argument('--walk', type=int, default=-1, help='D2D_TUNE_STEP_WALK (-1 = the library default)')
     ap.add_argument('--lpt', type=int, default=-1, help='D2D_TUNE_STEP_LPT (-1 = the library default)')
+    ap.add_argument('--path-loss', default='log2', choices=['log2', 'cost_hata'], help='log-distance with exponent 2 (1 / d^2 kernels) or COST-Hata (power-law kernels)')
     ap.add_argument('--no-export', action='store_true', help='d2d_set_export_actions(0): no decoded rb / pwr planes')
     a = ap.parse_args()
     if a.what == 'prepare':
         prepare(a.names)
     elif a.what == 'run':
-        run(a.workload, a.passes, not a.no_export, a.mode, a.walk, a.lpt)
+        run(a.workload, a.passes, not a.no_export, a.mode, a.walk, a.lpt, a.path_loss)
     else:
-        one(a.names[0], a.workload, not a.no_export, a.mode, a.walk, a.lpt)
+        one(a.names[0], a.workload, not a.no_export, a.mode, a.walk, a.lpt, a.path_loss)
