@@ -103,6 +103,46 @@ def test_two_links_per_thread_matches_one(native, shape, reward):
     sim.handle.close()
 
 
+@pytest.mark.parametrize('shape', [(6, 64, 64, 64), (5, 128, 128, 128), (4, 96, 192, 192), (3, 300, 512, 512)],
+                         ids=['128_links_one_wave', 'classes_of_128', 'classes_of_192_per_lane_records', '1024_links'])
+@pytest.mark.parametrize('mode', ['table_nt', 'table_export_plain', 'none_per_env'])
+def test_two_adjacent_links_per_thread_in_the_rollout_kernel(native, shape, mode):
+    """csrc/d2d_rollout.hip with LPT = 2: thread t carries links 2t and 2t + 1 - 8-byte action loads and plane stores, the
+    capacity tree of the one-link kernels rebuilt from the lane's own pair (the REWARD bits too are those of one link per
+    thread), the table rows through LDS as 1024-byte store instructions (simulator.py:89-154, reward_fn.py:27-44,
+    obs_fn.py:55-61).  Held to one link per thread and to the all-pairs sweep bit for bit, to the oracle at 1e-5, with
+    nontemporal and plain stores, with and without the decoded planes, and in the obs-less per-env-reward mode."""
+    b, rbs, cues, dues = shape
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=sum(shape))
+    raw[0, :12] = raw[0, 0]                                         # twelve links on one RB: the overflow pool, two links per thread
+    h = sim.handle
+    h.set_obs_mode(native.OBS_NONE if mode == 'none_per_env' else native.OBS_TABLE)
+    h.set_export_actions(mode == 'table_export_plain')
+    h.set_tuning(native.TUNE_STEP_NT_RESULTS, 0 if mode == 'table_export_plain' else 1)
+    if mode == 'none_per_env':
+        h.set_reward_layout(native.REWARD_PER_ENV)
+    bufs = [n for n in OUTS if not (mode == 'none_per_env' and n == 'BUF_OBS_TABLE') and not (mode != 'table_export_plain' and n in ('BUF_RB', 'BUF_PWR'))]
+    snaps = {}
+    for name, bucket, walk, lpt in (('all_pairs', False, 0, -1), ('one_link', True, 2, 1), ('two_links', True, 2, 2), ('auto', True, -1, -1)):
+        h.set_bucketing(bucket)
+        h.set_tuning(native.TUNE_STEP_WALK, walk)
+        h.set_tuning(native.TUNE_STEP_LPT, lpt)
+        if 'BUF_OBS_TABLE' in bufs:
+            h.upload(native.BUF_OBS_TABLE, np.full((b, cues + dues, 6), np.nan, np.float32))
+        sim.step_arrays(raw)
+        snaps[name] = {n: sim.fetch(getattr(native, n)).copy() for n in bufs}
+    _same(snaps, 'all_pairs')
+    tx, rx, ty = default_links(cues, dues)
+    ref = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(*orc.device_configs(cues, dues)[1:]), orc.PathLossSpec())
+    got = snaps['two_links']
+    assert rel_err(got['BUF_SINR_DB'], ref['sinr_db']) <= TOL and rel_err(got['BUF_CAPACITY'], ref['capacity_mbps']) <= TOL
+    rew = got['BUF_REWARD'] if mode == 'none_per_env' else got['BUF_REWARD'][:, 0]
+    assert rel_err(np.asarray(rew).reshape(b), ref['reward']) <= TOL
+    if 'BUF_OBS_TABLE' in bufs:
+        assert rel_err(got['BUF_OBS_TABLE'], ref['table']) <= TOL
+    h.close()
+
+
 def test_action_decode_is_exact_for_every_magnitude(native):
     """rb = a // P, pwr = a % P by one multiply-high below the bound stored with the magic, by division above it and for
     negatives (Python floor semantics): checked at the bound's edges, at 2^24, near 2^31 and below zero, for the CUE (24

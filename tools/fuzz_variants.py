@@ -33,7 +33,7 @@ def main():
     while time.time() - t0 < budget:
         kind = rng.integers(0, 4)
         if kind == 0:      # one link per thread, one env per workgroup (the rollout specialisation when N % 64 == 0)
-            n = int(rng.choice([64, 128, 192, 256, 512])); cues = n // 2; dues = n - cues
+            n = int(rng.choice([64, 128, 192, 256, 256, 512, 768, 1024])); cues = n // 2; dues = n - cues   # classes of 128 k links: two links per thread
         elif kind == 1:    # small envs sharing a workgroup
             cues, dues = int(rng.integers(0, 40)), int(rng.integers(1, 40))
         elif kind == 2:    # odd sizes
