@@ -121,7 +121,9 @@ def test_two_adjacent_links_per_thread_in_the_rollout_kernel(native, shape, mode
     h.set_tuning(native.TUNE_STEP_NT_RESULTS, 0 if mode == 'table_export_plain' else 1)
     if mode == 'none_per_env':
         h.set_reward_layout(native.REWARD_PER_ENV)
-    bufs = [n for n in OUTS if not (mode == 'none_per_env' and n == 'BUF_OBS_TABLE') and not (mode != 'table_export_plain' and n in ('BUF_RB', 'BUF_PWR'))]
+    bufs = [n for n in OUTS if not (mode == 'none_per_env' and n in ('BUF_OBS_TABLE', 'BUF_REWARD')) and not (mode != 'table_export_plain' and n in ('BUF_RB', 'BUF_PWR'))]
+    if mode == 'none_per_env':
+        bufs.append('BUF_REWARD_ENV')                               # the scalar once per env (d2d_set_reward_layout)
     snaps = {}
     for name, bucket, walk, lpt in (('all_pairs', False, 0, -1), ('one_link', True, 2, 1), ('two_links', True, 2, 2), ('auto', True, -1, -1)):
         h.set_bucketing(bucket)
@@ -136,7 +138,7 @@ def test_two_adjacent_links_per_thread_in_the_rollout_kernel(native, shape, mode
     ref = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, orc.device_columns(*orc.device_configs(cues, dues)[1:]), orc.PathLossSpec())
     got = snaps['two_links']
     assert rel_err(got['BUF_SINR_DB'], ref['sinr_db']) <= TOL and rel_err(got['BUF_CAPACITY'], ref['capacity_mbps']) <= TOL
-    rew = got['BUF_REWARD'] if mode == 'none_per_env' else got['BUF_REWARD'][:, 0]
+    rew = got['BUF_REWARD_ENV'] if mode == 'none_per_env' else got['BUF_REWARD'][:, 0]
     assert rel_err(np.asarray(rew).reshape(b), ref['reward']) <= TOL
     if 'BUF_OBS_TABLE' in bufs:
         assert rel_err(got['BUF_OBS_TABLE'], ref['table']) <= TOL
