@@ -222,12 +222,14 @@ typedef enum d2d_tuning {
                                       the launch); -1 = auto                                                    */
     D2D_TUNE_STEP_PREFETCH = 11,   /* software-prefetch distance of the action rows, in envs: -1 = auto (the envs
                                       resident on the chip at once), 0 = off                                    */
-    D2D_TUNE_STEP_LPT = 12,        /* links per thread held in registers: 1, 2 (half the waves per env), -1 = auto    */
+    D2D_TUNE_STEP_LPT = 12,        /* links per thread held in registers: 1, 2 (half the waves per env; the rollout
+                                      kernel: adjacent links 2t, 2t + 1, N a multiple of 128), -1 = auto            */
     D2D_TUNE_STEP_NT_RESULTS = 13, /* nontemporal result stores: 1 on (ignored with LinearObs, whose expansion kernel
                                       re-reads the table behind the step), 0 off, -1 = auto: on in the rollout kernel
                                       (d2d_rollout.hip), off elsewhere (no consistent gain measured there)         */
     D2D_TUNE_STEP_SCALAR_RECORDS = 14, /* rollout kernel: link records by one scalar load per wave when every aligned
-                                      group of 64 links has identical records; -1 = auto (on when legal), 0 off  */
+                                      group of 64 links (128 with two links per thread) has identical records;
+                                      -1 = auto (on when legal), 0 off                                           */
     D2D_TUNE_STEP_OBS_ROTATE = 15  /* fused LinearObs expansion: workgroup w starts at step (w * value) mod (its steps) of
                                       its (env, pass) store sequence and wraps, so that the concurrent stores of the
                                       resident workgroups are not one fixed stride apart; -1 = auto (29), 0 = off  */
