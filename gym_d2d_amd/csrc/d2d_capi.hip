@@ -460,7 +460,8 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // 4096 x 512, r4 HEAD -> rollout: obs-less 21.3 -> 19.3 us, compact table 27.7 -> 25.8, with the decoded planes 28.3 -> 27.3;
     // profiles/r5_ab_rollout_kernel.jsonl), so wherever it applies the lists are the default.
     const bool will_fuse = h->obs_mode == D2D_OBS_LINEAR && !h->obs_f64 && (h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128);
-    const bool rollout_cfg = action_mode == 0 && h->n_fixed == 0 && h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY && h->bucketing &&
+    const bool rollout_cfg = action_mode == 0 && h->n_fixed == 0 && h->bucketing &&
+                             (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON) &&
                              !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && h->tune_step_ablate == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
                              N % 64 == 0 && N <= 1024;

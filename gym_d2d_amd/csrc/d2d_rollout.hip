@@ -1,10 +1,11 @@
 // Rollout kernel for gfx950 (MI355X): the step of a learner's rollout - raw agent actions for every link, SystemCapacity
-// reward, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
+// (or the per-link Shannon) reward, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
 //
 // Reference path (file:line under /root/reference/src/gym_d2d): the same as csrc/d2d_step.hip -
 //   D2DEnv._decode_action envs/d2d_env.py:93-101, Actions.get_actions_by_rb actions.py:27-31,
 //   Simulator._calculate_sinrs / _snrs / _rates / _network_capacity simulator.py:89-154,
-//   SystemCapacityRewardFunction envs/reward_fn.py:27-44, LinearObsFunction's base table envs/obs_fn.py:55-61.
+//   SystemCapacityRewardFunction envs/reward_fn.py:27-44, ShannonRewardFunction :47-57, LinearObsFunction's base table
+//   envs/obs_fn.py:55-61.
 //
 // Why a kernel of its own (round 5): at 36 - 64 bytes per link the step is paced by the instructions a CU can issue, of every
 // kind (profiles/r4_elasticity_step_kernel.json; about one wave-instruction per cycle and CU), not by HBM.  The generic
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     const int tid = threadIdx.x, b = (int)blockIdx.x;
     const unsigned row = (unsigned)b * (unsigned)N;              // element offsets fit 32 bits (run_step refuses B * N * 24 >= 2^32)
     const bool cfg_export_actions = a.rb_out != nullptr;
+    const bool capacity_reward = a.reward_fn == 1;               // SystemCapacity (env-wide mean); else Shannon (per link)
     const unsigned EMPTY = (unsigned)N * 16u;                    // byte offset of the stand-in tuple link[N]
     const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
     const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u;
@@ -393,7 +395,10 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // per-lane rarities behind ONE wave-uniform branch: SystemCapacity's -1 rule (reward_fn.py:29-41: I am a non-D2D link whose
         // capacity is <= min_capacity and some D2D link shares my RB), a non-finite SINR / zero distance, a capacity too large for
         // the fixed-point sum (64 lanes x 3e7 stays below the 4e9 a 32.32 value holds)
-        const bool rule = type != LINK_SIDELINK && cap <= a.reward_param;
+        const bool rule = capacity_reward && type != LINK_SIDELINK && cap <= a.reward_param;
+        // ShannonRewardFunction (reward_fn.py:52-57) is per link: log2(1 + SINR), or -1 below the threshold.  (A plain 4-byte store
+        // per link, in here: the value would otherwise stay live across the other link's evaluation - a 65th VGPR.)
+        if (!capacity_reward) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = sinr_db >= a.reward_param ? sh : -1.0f;
         const bool nonfinite = MODE == PL_INV_SQUARE ? !(fabsf(sinr_db) <= 3.0e38f) : (dmin == 0 || !(fabsf(sinr_db) <= 3.0e38f));
         const bool huge = !(cap <= 3.0e7f);
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(rule | nonfinite | huge) != 0ull)) {
@@ -516,7 +521,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         const float total = (float)tot * 2.3283064365386963e-10f;
         const int viol = __hip_atomic_fetch_or((D2D_LDS(int)*)(L_FLAGS + 4u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const float r = (viol & 1) ? -1.0f : ((viol & 4) ? __int_as_float(0x7FC00000) : ((viol & 2) ? __int_as_float(0x7F800000) : total * a.inv_n));
-        if (a.reward_env) {                                            // D2D_REWARD_PER_ENV: the scalar once, not N copies
+        if (!capacity_reward) {
+            // per-link rewards are out already; the ticket only decides who publishes the env's flags
+        } else if (a.reward_env) {                                     // D2D_REWARD_PER_ENV: the scalar once, not N copies
             if (lane == 0) a.reward_env[b] = r;
         } else {
             const f32x4 r4 = {r, r, r, r};
