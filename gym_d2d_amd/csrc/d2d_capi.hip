@@ -462,7 +462,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     const bool will_fuse = h->obs_mode == D2D_OBS_LINEAR && !h->obs_f64 && (h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128);
     const bool rollout_cfg = action_mode == 0 && h->n_fixed == 0 && h->bucketing &&
                              (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON) &&
-                             !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && h->tune_step_ablate == 0 &&
+                             !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && (h->tune_step_ablate & ~8192) == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
                              N % 64 == 0 && N <= 1024;
     const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE || rollout_cfg);

@@ -46,6 +46,13 @@
 namespace d2d {
 
 #define RO_SLOTS 8
+// diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py --kernel rollout)
+#if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
+#define RO_STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0)                                                            \
+        a.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RO_STAMP(k) do { } while (0)
+#endif
 #define RO_ST(ptr, val) do { if (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 
 // LDS of one env (byte offsets; StepLds): 0 sum (u64) ... 60 dump (u16) | 64 flags[4]: env flags, reward bits, ticket, pool count
@@ -85,27 +92,19 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
     const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u;
 
+    RO_STAMP(0);
     // ---- prologue: the links' loads, issued before any LDS work or barrier (their latency overlaps pass 0)
     LinkRaw in[LPT];
     if (SREC && LPT == 2) {                                      // the thread's two actions: adjacent columns, one 8-byte load
         const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, fresh((row + 2u * (unsigned)tid) * 4u)));
         in[0].act0 = aa.x; in[LPT - 1].act0 = aa.y;
     }
-    // the records of a wave's 64 * LPT links are identical (StepArgs::rec_uniform; the host offers two links per thread only
-    // where that holds for aligned groups of 128): the whole record in ONE 64-byte scalar load per wave.  rec_grp holds a 64-byte
-    // row per group of 64 links, so the wave's first link index is the byte offset of its row.
-    i32x16 g;
-    if (SREC) g = scalar_load64(reinterpret_cast<const unsigned char*>(a.rec_grp) + (unsigned)(__builtin_amdgcn_readfirstlane(tid) * LPT));
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
         const int i = LPT * tid + u;
         if (SREC) {
             if (LPT == 1) in[u].act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
             in[u].act1 = 0;
-            in[u].ra = make_int4(g[2], 0, g[0], g[1]);
-            in[u].rb_ = make_float4(__int_as_float(g[4]), __int_as_float(g[5]), __int_as_float(g[6]), __int_as_float(g[7]));
-            in[u].rc = make_float4(__int_as_float(g[8]), __int_as_float(g[9]), __int_as_float(g[10]), __int_as_float(g[11]));
-            in[u].hh = make_float2(__int_as_float(g[12]), __int_as_float(g[13]));
             in[u].pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
         } else {
             in[u] = load_link(a, row, row, i, 0, 0, true, false, POWLAW);
@@ -134,8 +133,26 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     // nothing that consumes a loaded value may be scheduled above this barrier (the wave would sit on the HBM round trip
     // before pass 0 instead of behind it)
     __builtin_amdgcn_sched_barrier(0);
+    RO_STAMP(1);
     __syncthreads();
+    RO_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
+    // The records of a wave's 64 * LPT links are identical (StepArgs::rec_uniform; the host offers two links per thread only
+    // where that holds for aligned groups of 128): the whole record in ONE 64-byte scalar load per wave.  rec_grp holds a 64-byte
+    // row per group of 64 links, so the wave's first link index is the byte offset of its row.  Issued HERE, behind the barrier:
+    // a scalar load shares its counter with the LDS writes of pass 0, so in front of the barrier the wave would sit out this
+    // second round trip (kernel arguments -> table pointer -> record) before it may even arrive; here it hides under the links'
+    // loads, which are still in flight.
+    if (SREC) {
+        const i32x16 g = scalar_load64(reinterpret_cast<const unsigned char*>(a.rec_grp) + (unsigned)(__builtin_amdgcn_readfirstlane(tid) * LPT));
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            in[u].ra = make_int4(g[2], 0, g[0], g[1]);
+            in[u].rb_ = make_float4(__int_as_float(g[4]), __int_as_float(g[5]), __int_as_float(g[6]), __int_as_float(g[7]));
+            in[u].rc = make_float4(__int_as_float(g[8]), __int_as_float(g[9]), __int_as_float(g[10]), __int_as_float(g[11]));
+            in[u].hh = make_float2(__int_as_float(g[12]), __int_as_float(g[13]));
+        }
+    }
 
     // ---- pass 1: decode, stage the transmitter tuple, enter the RB's list
     int rb[LPT], pwr[LPT];
@@ -191,7 +208,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             RO_ST(reinterpret_cast<i32x2*>(at(a.pwr_out, oe)), (i32x2{pwr[0], pwr[LPT - 1]}));
         } else { RO_ST(at(a.rb_out, oe), rb[0]); RO_ST(at(a.pwr_out, oe), pwr[0]); }
     }
+    RO_STAMP(3);
     __syncthreads();
+    RO_STAMP(4);
 
     // software prefetch of the action rows of the env the workgroup `prefetch_envs` later will own (see step_kernel).  (The position
     // rows too - one dword per thread touches every line - measured: 20.9 -> 21.5 us with one link per thread, and a 65th VGPR with two)
@@ -437,6 +456,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             // a float sum gives - inf, or NaN once a NaN is among the parts
             if (huge) lds_atomic_or(L_FLAGS + 4u, cap != cap ? 4 : 2);
         }
+        RO_STAMP(5 + u);
     }
 
     // ---- results: the thread's LPT links are adjacent elements of every plane and adjacent rows of the table
@@ -488,6 +508,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         }
     }
 
+    RO_STAMP(7);
     // ---- reward: barrier-free ticket reduction (see step_kernel): DPP wave sum, 32.32 fixed-point capacity total in LDS (the
     // 64-bit integer sum does not depend on arrival order), the wave that draws the last ticket finishes the env
     const int lane = tid & 63;
@@ -531,6 +552,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         }
         if (lane == 0) a.env_flags[b] = __hip_atomic_fetch_or((D2D_LDS(int)*)(L_FLAGS), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    RO_STAMP(8);
 }
 
 hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, hipStream_t stream) {

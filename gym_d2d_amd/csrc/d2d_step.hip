@@ -90,7 +90,7 @@ size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lp
 // result stores of the rollout kernel: nontemporal when nothing re-reads them from L2 right behind this launch (OPT_NT)
 #define ST(ptr, val) do { if (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 #ifndef D2D_STEP_ABLATE
-#define D2D_STEP_ABLATE 0       /* diagnostic build: honour StepArgs::ablate (tools/ab_step.py ablate) */
+#define D2D_STEP_ABLATE 0       /* diagnostic build: honour StepArgs::ablate (parts of the kernel skipped; round 2 - 4 studies) */
 #endif
 #define ABL(bit) (D2D_STEP_ABLATE && (a.ablate & (bit)))
 // diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py)

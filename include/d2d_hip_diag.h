@@ -4,7 +4,7 @@
  *
  *  (1) tuning keys / values that only a DIAGNOSTIC build of libd2d_hip.so accepts
  *      (D2D_BUILD_DIAG=1 python -m gym_d2d_amd.build; a release build answers D2D_ERR_UNSUPPORTED): the A/B shapes the
- *      kernels were tuned against and the ablation switch of tools/ab_step.py, tools/elasticity.py, tools/phase_times.py;
+ *      kernels were tuned against, the ablation switch of the generic step kernel and the phase stamps of tools/phase_times.py;
  *  (2) the write-ceiling probe, a library of its own (libd2d_probe.so, csrc/d2d_probe.hip): what bench.py's
  *      `box_write_ceiling` and the placement studies under profiles/ were measured with.
  */

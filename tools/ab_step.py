@@ -3,7 +3,6 @@
 
     python tools/ab_step.py stress     # 4096 x 512, compact-obs mode: mask walk vs all-pairs, per reward fn (the RB-sorted
                                        # variant of round 2 lives in git history; its A/B is profiles/r2_ab_step_variants_stress.jsonl)
-    python tools/ab_step.py ablate     # diagnostic build only (D2D_BUILD_DIAG=1): parts of the kernel skipped
     python tools/ab_step.py default    # 1024 x 50, LinearObs: envs per workgroup x fused obs x block size
     python tools/ab_step.py halves     # 1024 x 50: one env of 1024 vs two of 512 on one / two streams (wall clock per 1024 env-steps)
 
@@ -114,34 +113,6 @@ def scale(args):
         torch.cuda.empty_cache()
 
 
-def ablate(args):
-    """Diagnostic builds of the same kernel with parts skipped (D2D_TUNE_STEP_ABLATE): where the time goes."""
-    b, c, p, r = 4096, 256, 256, 256
-    env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
-    env.reset(seed=1)
-    h = env.simulator.handle
-    act = torch.randint(0, r * 21, (64, b, c + p), device=env.device, dtype=torch.int32)      # fresh actions per launch
-    names = {0: 'full', 1: '-walk', 3: '-walk -mask_build', 7: '-walk -mask_build -mask_clear', 8: '-result_stores',
-             16: '-table_store', 32: '-rb_pwr_stores', 56: '-all_stores', 63: 'loads + decode + math only',
-             63 + 64: 'loads + decode + math only, no pass-0/1 barriers', 63 + 128: 'math only: per-env loads hit L2 (env 0)',
-             63 + 192: 'math only, L2 loads, no pass-0/1 barriers', 128: 'full, but per-env loads hit L2 (env 0)',
-             256: 'launch + prologue loads + pass 0 only', 256 + 4: 'launch + prologue loads only (no mask clear)',
-             256 + 4 + 128: 'launch + L2 loads only', 256 + 4 + 64: 'launch + prologue loads, no barrier',
-             512: 'through pass 1 (decode, staging, mask build)', 1024: 'workgroup launch only (exit at once)'}
-    variants = [(rw, 0, ab) for rw in (1, 0) for ab in names]
-    times = {v: [] for v in variants}
-    for rnd in range(args.rounds):
-        for v in variants:
-            h.set_reward(v[0], 0.0)
-            h.set_tuning(_native.TUNE_STEP_ABLATE, v[2])
-            times[v].append(timed(h, act, 32))
-    h.set_tuning(_native.TUNE_STEP_ABLATE, 0)
-    for v in variants:
-        emit({'sweep': 'stress_ablation', 'reward_fn': v[0], 'variant': v[1], 'skipped': names[v[2]],
-              'median_us': round(statistics.median(times[v]), 2)}, args.out)
-    env.close()
-
-
 def default(args):
     b, c, p, r = 1024, 25, 25, 25
     env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': LinearObsFunction}, num_envs=b,
@@ -211,9 +182,9 @@ def halves(args):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['stress', 'default', 'halves', 'ablate', 'scale'])
+    ap.add_argument('what', choices=['stress', 'default', 'halves', 'scale'])
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--quick', action='store_true', help='stress: only the mask walk and the member lists')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
-    {'stress': stress, 'default': default, 'halves': halves, 'ablate': ablate, 'scale': scale}[a.what](a)
+    {'stress': stress, 'default': default, 'halves': halves, 'scale': scale}[a.what](a)
