@@ -93,26 +93,6 @@ def stress(args):
     env.close()
 
 
-def scale(args):
-    """Steady state vs ramp: the same step at 1024 ... 16384 envs x 512 links, compact-obs mode.  A launch of B envs costs
-    t(B) = t0 + B / rate: the slope is the sustained rate, t0 what launching, the first loads and the last stores' drain cost."""
-    c, p, r = 256, 256, 256
-    for b in (1024, 2048, 4096, 8192, 16384):
-        env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': OwnLinkObsFunction}, num_envs=b)
-        env.reset(seed=1)
-        h = env.simulator.handle
-        act = torch.randint(0, r * 21, (max(8, 65536 // b), b, c + p), device=env.device, dtype=torch.int32)
-        for export in (1, 0):
-            h.set_export_actions(bool(export))
-            t = [timed(h, act, 32) for _ in range(args.rounds)]
-            med = statistics.median(t)
-            emit({'sweep': 'stress_scale_envs', 'envs': b, 'export_rb_pwr': export, 'median_us': round(med, 2), 'min_us': round(min(t), 2),
-                  'us_per_4096_envs': round(med * 4096 / b, 2), 'algorithmic_GBps': round(b * (c + p) * 64.0 / med / 1e3)}, args.out)
-        env.close()
-        del env, act
-        torch.cuda.empty_cache()
-
-
 def default(args):
     b, c, p, r = 1024, 25, 25, 25
     env = VecD2DEnv({'num_rbs': r, 'num_cues': c, 'num_due_pairs': p, 'obs_fn': LinearObsFunction}, num_envs=b,
@@ -182,9 +162,9 @@ def halves(args):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['stress', 'default', 'halves', 'scale'])
+    ap.add_argument('what', choices=['stress', 'default', 'halves'])
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--quick', action='store_true', help='stress: only the mask walk and the member lists')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
-    {'stress': stress, 'default': default, 'halves': halves, 'scale': scale}[a.what](a)
+    {'stress': stress, 'default': default, 'halves': halves}[a.what](a)
