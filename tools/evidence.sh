@@ -8,14 +8,8 @@
 tag=${1:-r5}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${tag}_evidence; mkdir -p $O; cd $R
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/tests.log 2>&1; echo "gpu tests rc=$? $(tail -1 $O/tests.log)" > $O/summary.txt
-# the driver-like line (headline + core_mode + other_workloads + flat scalars), then the stand-alone configurations
-: > profiles/${tag}_bench_lines.jsonl
-for args in "" "--workload default" "--workload plugin" "--obs table --no-export" "--obs table" \
-            "--obs none --no-export --reward-per-env" "--obs-dtype float64 --steps 30"; do
-  extra="--no-cpu-baseline --no-single-env-latency --no-extras"; [ -z "$args" ] && extra=""
-  timeout 1200 python bench.py $args $extra 2>> $O/bench.err | tail -1 >> profiles/${tag}_bench_lines.jsonl
-done
-# rocprofv3: kernel trace + PMC passes per workload (tools/profile_bench.sh; bench.py quotes `traffic` from these summaries)
+# rocprofv3 first: kernel trace + PMC passes per workload (tools/profile_bench.sh); bench.py quotes `roofline.traffic` from the
+# summaries of THESE sources (digest match), so the lines below all carry it
 bash tools/profile_bench.sh $tag stress linear 100 > $O/prof_stress_linear.log 2>&1
 bash tools/profile_bench.sh $tag stress linear 30 --obs-dtype float64 > $O/prof_stress_linear_f64.log 2>&1
 bash tools/profile_bench.sh $tag stress table 1000 --no-export > $O/prof_stress_table.log 2>&1
@@ -23,18 +17,18 @@ bash tools/profile_bench.sh $tag stress table 1000 > $O/prof_stress_table_export
 bash tools/profile_bench.sh $tag stress none 1000 --no-export --reward-per-env > $O/prof_stress_none.log 2>&1
 bash tools/profile_bench.sh $tag default linear 4000 > $O/prof_default_linear.log 2>&1
 bash tools/profile_bench.sh $tag plugin table 1000 > $O/prof_plugin_table.log 2>&1
-# the line once more, now that the PMC summaries of THESE sources exist: `roofline.traffic` is quoted from them
-timeout 1200 python bench.py 2>> $O/bench.err | tail -1 > $O/bench_default_with_traffic.json
+# the driver-like line (headline + core_mode + other_workloads + flat scalars), then the stand-alone configurations
+: > profiles/${tag}_bench_lines.jsonl
+for args in "" "--workload default" "--workload plugin" "--obs table --no-export" "--obs table" \
+            "--obs none --no-export --reward-per-env" "--obs-dtype float64 --steps 30"; do
+  extra="--no-cpu-baseline --no-single-env-latency --no-extras"; [ -z "$args" ] && extra=""
+  timeout 1200 python bench.py $args $extra 2>> $O/bench.err | tail -1 >> profiles/${tag}_bench_lines.jsonl
+done
 python3 - "$tag" <<'PY'
 import json, sys
-tag = sys.argv[1]
-lines = [l for l in open(f'profiles/{tag}_bench_lines.jsonl') if l.strip()]
-try:
-    lines[0] = open(f'gpurun_out/{tag}_evidence/bench_default_with_traffic.json').read().strip() + '\n'
-except Exception as exc:
-    print('kept the first default line:', exc)
-open(f'profiles/{tag}_bench_lines.jsonl', 'w').writelines(lines)
-for l in lines:
+for l in open(f'profiles/{sys.argv[1]}_bench_lines.jsonl'):
+    if not l.strip():
+        continue
     d = json.loads(l)
     r = d['roofline']
     print(d['config']['workload'][:40], d['config'].get('obs_mode'), d.get('obs_dtype'), 'ms/step %.4f' % d['ms_per_step'], r['kernel'],
