@@ -464,7 +464,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
                              (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON) &&
                              !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && (h->tune_step_ablate & ~8192) == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
-                             N % 64 == 0 && N <= 1024;
+                             (N % 64 == 0 || N > 128) && N <= 1024;      // (no multiple of 64: padded, above the sizes whose envs share a workgroup)
     const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE || rollout_cfg);
     s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (lists_pay ? 2 : 0);
 
@@ -526,7 +526,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
             d2d::rollout_lds_layout(N, s.R, (int)h->mode, &rlds);
             if (rlds.env_bytes <= 64 * 1024) {
                 s.rollout = 1; s.lds = rlds;
-                lpt = rl; tpe = N / rl; W = 0; s.lpt = lpt;
+                lpt = rl; tpe = ((N / rl + 63) / 64) * 64; W = 0; s.lpt = lpt;
                 if (h->tune_step_nt < 0 && h->obs_mode != D2D_OBS_LINEAR) s.nt_results = 1;      // auto: on, see above
             }
         }

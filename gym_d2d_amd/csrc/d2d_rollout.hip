@@ -31,6 +31,8 @@
 //     lane's own pair (wave_sum_halves);
 //   * with two links per thread the TABLE ROWS (24 bytes per link) leave through LDS, so that every store instruction writes
 //     1024 contiguous bytes (see the results section: 26.7 -> 24.5 us in the table mode).
+//   * a link count that is no multiple of 64 (OPT_PAD) is padded to the next one with threads that SHADOW the last link (see the top of
+//     the kernel), and its reward is reduced as the generic kernels reduce it for such shapes;
 // Same arithmetic as step_kernel everywhere else (tests/test_gpu_step_variants.py holds the two bit-identical).
 //
 // Worst case: an env whose actions pile more than eight links on one RB costs its members a scan of the pool (<= N entries);
@@ -64,6 +66,8 @@ void rollout_lds_layout(int N, int R, int mode, StepLds* out) {
     off = (off + 15u) & ~15u;
     out->lists = off; off += ((unsigned)R + 1u) * 16u + (((unsigned)R + 1u + 3u) & ~3u) * 4u;
     out->pool = off; off += (unsigned)N * 8u;
+    off = (off + 15u) & ~15u;
+    out->aux = off; off += 64u;                                   // padded link counts: the waves' capacity sums (16 floats)
     out->env_bytes = (off + 15u) & ~15u;
 }
 
@@ -79,18 +83,24 @@ __device__ __forceinline__ void lds_atomic_or(unsigned addr, int bits) {
 
 template <int MODE, int OPT, int LPT>
 __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
-    constexpr bool SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0;
+    constexpr bool SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0, PAD = (OPT & OPT_PAD) != 0;
+    static_assert(!PAD || (LPT == 1 && !SREC), "a link count that is no multiple of 64: one link per thread, per-lane records");
     constexpr bool POWLAW = MODE == PL_POWER;
     static_assert(MODE == PL_INV_SQUARE || MODE == PL_POWER, "the rollout kernel serves the power laws");
     static_assert(LPT == 1 || LPT == 2, "one or two links per thread");
     const int N = a.N, R = a.R, TPE = a.tpe;                     // N == LPT * TPE == LPT * blockDim.x; thread t: links LPT * t + u
     const int tid = threadIdx.x, b = (int)blockIdx.x;
+    // OPT_PAD: N is no multiple of 64 and TPE the next one.  A thread beyond the last link SHADOWS link N - 1 - same loads, same
+    // arithmetic, the same values stored to the same addresses - except that it enters no list and adds no capacity: two guards
+    // instead of a predicate on every access.
+    const auto link_of = [&](int u) { const int i = LPT * tid + u; return PAD ? min(i, N - 1) : i; };
+    const bool shadow = PAD && tid >= N;
     const unsigned row = (unsigned)b * (unsigned)N;              // element offsets fit 32 bits (run_step refuses B * N * 24 >= 2^32)
     const bool cfg_export_actions = a.rb_out != nullptr;
     const bool capacity_reward = a.reward_fn == 1;               // SystemCapacity (env-wide mean); else Shannon (per link)
     const unsigned EMPTY = (unsigned)N * 16u;                    // byte offset of the stand-in tuple link[N]
     const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
-    const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u;
+    const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u, L_RED = a.lds.aux;
 
     RO_STAMP(0);
     // ---- prologue: the links' loads, issued before any LDS work or barrier (their latency overlaps pass 0)
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
-        const int i = LPT * tid + u;
+        const int i = link_of(u);
         if (SREC) {
             if (LPT == 1) in[u].act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
             in[u].act1 = 0;
@@ -129,6 +139,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             if (POWLAW) lds_put<f32x2>(L_EXPO + (EMPTY >> 1), f32x2{-1.0f, 0.0f});
         }
         if (tid < 5) lds_put<u32x4>((unsigned)tid * 16u, u32x4{0u, 0u, 0u, 0u});          // sum, dump, flags[4]: 80 bytes
+        if (PAD && tid >= 8 && tid < 12) lds_put<u32x4>(L_RED + (unsigned)(tid - 8) * 16u, u32x4{0u, 0u, 0u, 0u});
     }
     // nothing that consumes a loaded value may be scheduled above this barrier (the wave would sit on the HBM round trip
     // before pass 0 instead of behind it)
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     unsigned slot[LPT], row_off[LPT];
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
-        const int i = LPT * tid + u;
+        const int i = link_of(u);
         const unsigned my_off = (unsigned)i << 4;
         const unsigned P = __float_as_uint(in[u].rc.w) & 0xFFFFu;
         // the host keeps the bound below R * P (refresh_tables): an action inside it decodes to rb < R by one multiply-high
@@ -186,14 +197,14 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         if (POWLAW) lds_put<f32x2>(L_EXPO + (my_off >> 1), f32x2{in[u].hh.x, in[u].hh.y});
         pwr[u] = pw;
         row_off[u] = L_SLOTS + rbc * 16u;
-        slot[u] = lds_atomic_inc(L_CNT + rbc * 4u);
+        slot[u] = shadow ? 0u : lds_atomic_inc(L_CNT + rbc * 4u);
     }
     // (the slot numbers of the thread's links come back together: one LDS round trip, not one per link)
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
-        const int i = LPT * tid + u;
+        const int i = link_of(u);
         const bool ovf = slot[u] >= (unsigned)RO_SLOTS;
-        lds_put<unsigned short>(ovf ? L_DUMP : row_off[u] + slot[u] * 2u, (unsigned short)((unsigned)i << 4));
+        if (!shadow) lds_put<unsigned short>(ovf ? L_DUMP : row_off[u] + slot[u] * 2u, (unsigned short)((unsigned)i << 4));
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(ovf) != 0ull)) {
             if (ovf) {                                           // the ninth and later links of an RB: the env's overflow pool
                 const unsigned ps = lds_atomic_inc(L_FLAGS + 12u);
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         }
     }
     if (cfg_export_actions) {                                    // the decoded planes: the thread's LPT adjacent elements in one store
-        const unsigned oe = fresh((row + (unsigned)(LPT * tid)) * 4u);
+        const unsigned oe = fresh((row + (unsigned)link_of(0)) * 4u);
         if (LPT == 2) {
             RO_ST(reinterpret_cast<i32x2*>(at(a.rb_out, oe)), (i32x2{rb[0], rb[LPT - 1]}));
             RO_ST(reinterpret_cast<i32x2*>(at(a.pwr_out, oe)), (i32x2{pwr[0], pwr[LPT - 1]}));
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     {
         const int bq = b + a.prefetch_envs;
         const int bp = bq < a.B ? bq : a.B - 1;
-        const unsigned op = fresh(((unsigned)bp * (unsigned)N + (unsigned)(LPT * tid)) * 4u);
+        const unsigned op = fresh(((unsigned)bp * (unsigned)N + (unsigned)link_of(0)) * 4u);
         if (LPT == 2) { const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, op)); pf = aa.x ^ aa.y; }
         else pf = *at(a.actions, op);
     }
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     float caps[LPT], rates[LPT], sinrs[LPT], snrs[LPT];
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
-        const int i = LPT * tid + u;
+        const int i = link_of(u);
         const unsigned my_off = (unsigned)i << 4;
         const int type = (in[u].ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const float2 rx = make_float2(in[u].pos.z, in[u].pos.w);
@@ -454,14 +465,14 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             if (my_flags) lds_atomic_or(L_FLAGS, my_flags);
             // a non-finite (or absurdly large) capacity cannot go through the fixed-point accumulator: the env's reward is then what
             // a float sum gives - inf, or NaN once a NaN is among the parts
-            if (huge) lds_atomic_or(L_FLAGS + 4u, cap != cap ? 4 : 2);
+            if (huge && !PAD) lds_atomic_or(L_FLAGS + 4u, cap != cap ? 4 : 2);   // (padded: a float sum, which carries inf / NaN itself)
         }
         RO_STAMP(5 + u);
     }
 
     // ---- results: the thread's LPT links are adjacent elements of every plane and adjacent rows of the table
     {
-        const unsigned o4 = fresh((row + (unsigned)(LPT * tid)) * 4u);
+        const unsigned o4 = fresh((row + (unsigned)link_of(0)) * 4u);
         if (LPT == 2) {
             RO_ST(reinterpret_cast<f32x2*>(at(a.sinr_db, o4)), (f32x2{sinrs[0], sinrs[LPT - 1]}));
             RO_ST(reinterpret_cast<f32x2*>(at(a.snr_db, o4)), (f32x2{snrs[0], snrs[LPT - 1]}));
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             RO_ST(at(a.cap, o4), caps[0]);
         }
         if (a.write_table) {                                         // obs_fn.py:57-60: (tx, rx, sinr, snr) per link, 24 bytes
-            const unsigned o4t = fresh((row + (unsigned)(LPT * tid)) * 4u);
+            const unsigned o4t = fresh((row + (unsigned)link_of(0)) * 4u);
             unsigned char* t = reinterpret_cast<unsigned char*>(at(a.table, (o4t << 2) + (o4t << 1)));
             if (LPT == 2) {                                          // 48 contiguous bytes
                 const float4 p0 = in[0].pos, p1 = in[LPT - 1].pos;
@@ -509,6 +520,24 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     }
 
     RO_STAMP(7);
+    if (PAD) {
+        // ---- reward for a link count that is no multiple of 64: what the generic kernels do for such shapes, operation for
+        // operation (their wave partition is this kernel's): the waves' float sums through LDS, one barrier, a fixed-order total
+        const float wsum = wave_sum(shadow ? 0.0f : caps[0]);
+        if ((tid & 63) == 0) lds_put<float>(L_RED + (unsigned)(tid >> 6) * 4u, wsum);
+        asm volatile("" ::"v"(pf));
+        __syncthreads();
+        float total = 0.0f;
+        for (int w = 0; w < (TPE + 255) >> 8; ++w) { const f32x4 v = lds_get<f32x4>(L_RED + (unsigned)w * 16u); total += (v.x + v.y) + (v.z + v.w); }
+        if (capacity_reward) {
+            const float r = lds_get<int>(L_FLAGS + 4u) ? -1.0f : total * a.inv_n;
+            if (a.reward_env) { if (tid == 0) a.reward_env[b] = r; }
+            else *at(a.reward, fresh((row + (unsigned)link_of(0)) * 4u)) = r;
+        }
+        if (tid == 0) a.env_flags[b] = lds_get<int>(L_FLAGS);
+        RO_STAMP(8);
+        return;
+    }
     // ---- reward: barrier-free ticket reduction (see step_kernel): DPP wave sum, 32.32 fixed-point capacity total in LDS (the
     // 64-bit integer sum does not depend on arrival order), the wave that draws the last ticket finishes the env
     const int lane = tid & 63;
@@ -521,7 +550,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         float lo, hi;
         wave_sum_halves(caps[0] + caps[LPT - 1], lo, hi);
         fixed = to_fixed_32_32(lo) + to_fixed_32_32(hi);
-    } else fixed = to_fixed_32_32(wave_sum(caps[0]));
+    } else fixed = to_fixed_32_32(wave_sum(shadow ? 0.0f : caps[0]));
     asm volatile("" ::"v"(pf));                                      // the prefetched words are consumed here (no instruction)
     // This wave's LDS atomics above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
     // above it in the instruction stream.  The last wave's reads below stay behind its own ticket (acquire).
@@ -583,7 +612,10 @@ hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_thr
         case OPT_NT: D2D_RO_1(M, OPT_NT, L); break;                                                      \
         default: D2D_RO_1(M, OPT_SREC | OPT_NT, L); break;                                               \
     }
-#define D2D_RO(M) do { if (a.lpt == 2) { D2D_RO_L(M, 2) } else { D2D_RO_L(M, 1) } } while (0)
+#define D2D_RO(M) do {                                                                                   \
+        if (opt & OPT_PAD) { if (opt & OPT_NT) D2D_RO_1(M, OPT_PAD | OPT_NT, 1); else D2D_RO_1(M, OPT_PAD, 1); }  \
+        else if (a.lpt == 2) { D2D_RO_L(M, 2) } else { D2D_RO_L(M, 1) }                                  \
+    } while (0)
     if (mode == PL_INV_SQUARE) D2D_RO(PL_INV_SQUARE); else D2D_RO(PL_POWER);
 #undef D2D_RO
 #undef D2D_RO_L

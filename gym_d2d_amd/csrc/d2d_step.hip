@@ -837,8 +837,8 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
                      (a.walk == 0 || lists) && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
                      a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
     const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0);
+    if (a.rollout) return launch_rollout(a, mode, a.N % 64 ? (hot_opt & OPT_NT) | OPT_PAD : hot_opt, block_threads, stream);
     // the rollout configuration with member lists has a kernel of its own (d2d_rollout.hip; chosen by run_step)
-    if (a.rollout) return launch_rollout(a, mode, hot_opt, block_threads, stream);
     // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&

@@ -352,5 +352,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define OPT_LISTS 1      /* generic kernels: per-RB member lists instead of the masks (StepArgs::walk == 2) */
 #define OPT_SREC 2       /* rollout kernel: link records by scalar loads (StepArgs::rec_uniform) */
 #define OPT_NT 4         /* rollout kernel: nontemporal result stores (StepArgs::nt_results) */
+#define OPT_PAD 8        /* rollout kernel: N is no multiple of 64 (threads beyond the last link shadow it) */
 
 }  // namespace d2d
