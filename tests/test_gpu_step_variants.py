@@ -204,8 +204,10 @@ def test_rollout_specialisations_are_bit_identical_to_the_generic_kernel(native,
 
 # shapes: lists never overflow / a few envs overflow / every env overflows (25, 18 links per RB) / N > 512 (two links per
 # thread) / one link per RB / a single RB
+# (envs, RBs, CUEs, DUE pairs).  130, 191, 129 and 1023 links: the rollout kernel padded to the next multiple of 64 (a crowded one,
+# two sparse ones at the edges of its range, the largest)
 SHAPES = [(33, 25, 25, 25), (64, 256, 256, 256), (16, 4, 40, 60), (8, 7, 0, 130), (5, 300, 100, 91), (9, 1, 64, 64),
-          (6, 64, 300, 400), (3, 500, 600, 600)]
+          (6, 64, 300, 400), (3, 500, 600, 600), (7, 40, 64, 65), (3, 256, 511, 512)]
 
 
 @pytest.mark.parametrize('shape', SHAPES)

@@ -37,7 +37,8 @@ def main():
         elif kind == 1:    # small envs sharing a workgroup
             cues, dues = int(rng.integers(0, 40)), int(rng.integers(1, 40))
         elif kind == 2:    # odd sizes
-            cues, dues = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+            hi = 300 if rng.random() < 0.6 else 520               # up to 1024 links: the padded rollout kernel; beyond: the generic lists
+            cues, dues = int(rng.integers(1, hi)), int(rng.integers(1, hi))
         else:              # beyond the masks
             cues, dues = int(rng.integers(500, 1024)), int(rng.integers(525, 1024))
         rbs = int(rng.choice([1, 2, 5, 16, 64, 300, max(1, (cues + dues) // 2)]))
