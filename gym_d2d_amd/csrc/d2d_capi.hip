@@ -460,7 +460,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // 4096 x 512, r4 HEAD -> rollout: obs-less 21.3 -> 19.3 us, compact table 27.7 -> 25.8, with the decoded planes 28.3 -> 27.3;
     // profiles/r5_ab_rollout_kernel.jsonl), so wherever it applies the lists are the default.
     const bool will_fuse = h->obs_mode == D2D_OBS_LINEAR && !h->obs_f64 && (h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128);
-    const bool rollout_cfg = action_mode == 0 && h->n_fixed == 0 && h->bucketing &&
+    const bool rollout_cfg = action_mode == 0 && (h->n_fixed == 0 || (h->n_fixed < N && h->col_mode == 0)) && h->bucketing &&   // fixed links: a prefix
                              (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON) &&
                              !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && (h->tune_step_ablate & ~8192) == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
@@ -521,6 +521,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         int rl = h->tune_step_lpt > 0 ? h->tune_step_lpt : (h->rec_uniform128 && s.rec_uniform && h->mode == d2d::PL_INV_SQUARE ? 2 : 1);
         if (rl != 2 || N % 128 != 0) rl = 1;
         if (rl == 2 && !h->rec_uniform128) s.rec_uniform = false;     // forced by the tuning key on other records: per-lane records
+        if (h->n_fixed > 0) { s.rec_uniform = false; rl = 1; }         // fixed actions live in per-link records: one link per thread
         {
             d2d::StepLds rlds;
             d2d::rollout_lds_layout(N, s.R, (int)h->mode, &rlds);

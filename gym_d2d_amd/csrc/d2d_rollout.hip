@@ -1,5 +1,5 @@
-// Rollout kernel for gfx950 (MI355X): the step of a learner's rollout - raw agent actions for every link, SystemCapacity
-// (or the per-link Shannon) reward, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
+// Rollout kernel for gfx950 (MI355X): the step of a learner's rollout - raw agent actions for every link (or all but a prefix with
+// fixed actions: traffic-model CUEs), SystemCapacity (or the per-link Shannon) reward, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
 //
 // Reference path (file:line under /root/reference/src/gym_d2d): the same as csrc/d2d_step.hip -
 //   D2DEnv._decode_action envs/d2d_env.py:93-101, Actions.get_actions_by_rb actions.py:27-31,
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     const auto link_of = [&](int u) { const int i = LPT * tid + u; return PAD ? min(i, N - 1) : i; };
     const bool shadow = PAD && tid >= N;
     const unsigned row = (unsigned)b * (unsigned)N;              // element offsets fit 32 bits (run_step refuses B * N * 24 >= 2^32)
+    const int n_fixed = SREC ? 0 : a.n_fixed;                    // scalar records: the host offers them without fixed links only
+    const unsigned act_row = SREC ? row : (unsigned)b * (unsigned)a.act_stride;
     const bool cfg_export_actions = a.rb_out != nullptr;
     const bool capacity_reward = a.reward_fn == 1;               // SystemCapacity (env-wide mean); else Shannon (per link)
     const unsigned EMPTY = (unsigned)N * 16u;                    // byte offset of the stand-in tuple link[N]
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             in[u].act1 = 0;
             in[u].pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
         } else {
-            in[u] = load_link(a, row, row, i, 0, 0, true, false, POWLAW);
+            // (per-lane records: a PREFIX of the links may carry fixed actions - traffic-model CUEs, traffic_model.py:15-32 - and the
+            // action array then has a column per remaining link only)
+            in[u] = load_link(a, row, act_row, i, 0, 0, false, false, POWLAW);
         }
     }
 
@@ -176,14 +180,16 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         const unsigned my_off = (unsigned)i << 4;
         const unsigned P = __float_as_uint(in[u].rc.w) & 0xFFFFu;
         // the host keeps the bound below R * P (refresh_tables): an action inside it decodes to rb < R by one multiply-high
-        const bool bad = (unsigned)in[u].act0 > (unsigned)in[u].ra.w;
+        // (a link with a fixed action takes the rare arm too: its record holds (rb, pwr) where the others hold the magic and the bound)
+        const bool fixed = !SREC && (in[u].ra.x & D2D_REC_FIXED_BIT) != 0;
+        const bool bad = fixed | ((unsigned)in[u].act0 > (unsigned)in[u].ra.w);
         rb[u] = (int)__umulhi((unsigned)in[u].act0, (unsigned)in[u].ra.z);
         int pw = in[u].act0 - (int)__umul24((unsigned)rb[u], P);
         oor[u] = false;
         unsigned rbc = (unsigned)rb[u];                          // the list this link enters
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(bad) != 0ull)) {
             if (bad) {                                           // negative, beyond R * P, or beyond the multiply-high range: divide
-                decode_link(a, in[u], row, rb[u], pw, 0, true);
+                decode_link(a, in[u], act_row, rb[u], pw, 0, SREC);
                 oor[u] = (unsigned)rb[u] >= (unsigned)R;         // accepted like the reference does (d2d_env.py:94-96)
                 rbc = oor[u] ? (unsigned)R : (unsigned)rb[u];    // row R: where links that enter no list are parked
                 if (oor[u]) lds_atomic_or(L_FLAGS, FLAG_RB_OOR);
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     {
         const int bq = b + a.prefetch_envs;
         const int bp = bq < a.B ? bq : a.B - 1;
-        const unsigned op = fresh(((unsigned)bp * (unsigned)N + (unsigned)link_of(0)) * 4u);
+        const unsigned op = fresh(((unsigned)bp * (SREC ? (unsigned)N : (unsigned)a.act_stride) + (unsigned)max(link_of(0) - n_fixed, 0)) * 4u);
         if (LPT == 2) { const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, op)); pf = aa.x ^ aa.y; }
         else pf = *at(a.actions, op);
     }
