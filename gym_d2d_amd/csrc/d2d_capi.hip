@@ -461,7 +461,8 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // profiles/r5_ab_rollout_kernel.jsonl), so wherever it applies the lists are the default.
     const bool will_fuse = h->obs_mode == D2D_OBS_LINEAR && !h->obs_f64 && (h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128);
     const bool rollout_cfg = action_mode == 0 && (h->n_fixed == 0 || (h->n_fixed < N && h->col_mode == 0)) && h->bucketing &&   // fixed links: a prefix
-                             (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON) &&
+                             (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON ||
+                              h->reward_fn == D2D_REWARD_CUE_SINR_SHANNON) &&
                              !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && (h->tune_step_ablate & ~8192) == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
                              (N % 64 == 0 || N > 128) && N <= 1024;      // (no multiple of 64: padded, above the sizes whose envs share a workgroup)
@@ -495,7 +496,9 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // per-RB member lists (walk 2): any N whose links sit in registers; an env that overflows a list falls back to the masks
     // when they exist, else to the all-pairs sweep
     int lists = h->bucketing && s.walk == 2 && lpt > 0 && s.reward_fn != D2D_REWARD_CUE_SINR_SHANNON;
-    if (s.walk == 2 && !lists) s.walk = 0;
+    // (the rollout kernel has its own way with CueSinrShannon; the generic kernels' lists have none)
+    const bool rollout_wanted = h->bucketing && s.walk == 2 && rollout_cfg && h->col_mode == 0;
+    if (s.walk == 2 && !lists && !rollout_wanted) s.walk = 0;
     int W = 0;
     if (h->bucketing && lpt > 0 && N <= 1024) {
         W = (N + 31) / 32;
@@ -509,7 +512,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, &s.lds);
     // The rollout kernel (d2d_rollout.hip): raw agent actions for every link, SystemCapacity, one env per workgroup, a power-law
     // path loss, member lists wanted.  Its own LDS layout: no masks, 17 KB per env at 512 links on 256 RBs.
-    if (lists && s.walk == 2 && rollout_cfg && h->col_mode == 0) {
+    if (rollout_wanted) {
         // One link per thread, or two ADJACENT ones (links 2t and 2t + 1, N / 2 threads per env): every per-wave instruction - the
         // scalar record load, barriers, ballots, the wave reduction, the ticket - is paid once per 128 links, half as many waves are
         // launched, and a thread's two results are one 8-byte element of every plane and 48 contiguous bytes of the table.  Two
@@ -522,9 +525,10 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         if (rl != 2 || N % 128 != 0) rl = 1;
         if (rl == 2 && !h->rec_uniform128) s.rec_uniform = false;     // forced by the tuning key on other records: per-lane records
         if (h->n_fixed > 0) { s.rec_uniform = false; rl = 1; }         // fixed actions live in per-link records: one link per thread
+        if (s.reward_fn == D2D_REWARD_CUE_SINR_SHANNON) rl = 1;        // its second look at the RB's members: one link per thread
         {
             d2d::StepLds rlds;
-            d2d::rollout_lds_layout(N, s.R, (int)h->mode, &rlds);
+            d2d::rollout_lds_layout(N, s.R, (int)h->mode, s.reward_fn, &rlds);
             if (rlds.env_bytes <= 64 * 1024) {
                 s.rollout = 1; s.lds = rlds;
                 lpt = rl; tpe = ((N / rl + 63) / 64) * 64; W = 0; s.lpt = lpt;

@@ -118,7 +118,7 @@ struct ObsArgs {
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, hipStream_t stream);
-void rollout_lds_layout(int N, int R, int mode, StepLds* out);
+void rollout_lds_layout(int N, int R, int mode, int reward_fn, StepLds* out);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
 size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists);
 void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out);

@@ -1,10 +1,10 @@
 // Rollout kernel for gfx950 (MI355X): the step of a learner's rollout - raw agent actions for every link (or all but a prefix with
-// fixed actions: traffic-model CUEs), SystemCapacity (or the per-link Shannon) reward, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
+// fixed actions: traffic-model CUEs), any of the three rewards, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
 //
 // Reference path (file:line under /root/reference/src/gym_d2d): the same as csrc/d2d_step.hip -
 //   D2DEnv._decode_action envs/d2d_env.py:93-101, Actions.get_actions_by_rb actions.py:27-31,
 //   Simulator._calculate_sinrs / _snrs / _rates / _network_capacity simulator.py:89-154,
-//   SystemCapacityRewardFunction envs/reward_fn.py:27-44, ShannonRewardFunction :47-57, LinearObsFunction's base table
+//   SystemCapacityRewardFunction envs/reward_fn.py:27-44, ShannonRewardFunction :47-57, CueSinrShannonRewardFunction :60-78, LinearObsFunction's base table
 //   envs/obs_fn.py:55-61.
 //
 // Why a kernel of its own (round 5): at 36 - 64 bytes per link the step is paced by the instructions a CU can issue, of every
@@ -59,7 +59,7 @@ namespace d2d {
 
 // LDS of one env (byte offsets; StepLds): 0 sum (u64) ... 60 dump (u16) | 64 flags[4]: env flags, reward bits, ticket, pool count
 // | 80 link[N + 1] tuples | expo[N + 1] (power law) | slots[R + 1] (8 x u16) | cnt[R + 1] | pool[N] (rb, link)
-void rollout_lds_layout(int N, int R, int mode, StepLds* out) {
+void rollout_lds_layout(int N, int R, int mode, int reward_fn, StepLds* out) {
     std::memset(out, 0, sizeof(*out));
     unsigned off = LDS_HEAD_BYTES + ((unsigned)N + 1u) * 16u;
     out->expo = off; if (mode == PL_POWER) off += ((unsigned)N + 1u) * 8u;
@@ -68,6 +68,8 @@ void rollout_lds_layout(int N, int R, int mode, StepLds* out) {
     out->pool = off; off += (unsigned)N * 8u;
     off = (off + 15u) & ~15u;
     out->aux = off; off += 64u;                                   // padded link counts: the waves' capacity sums (16 floats)
+    out->rx = off;                                                // CueSinrShannon: per link "a non-D2D link below the threshold" (+ one for the stand-in)
+    if (reward_fn == 3) off += ((unsigned)N + 1u) * 4u;
     out->env_bytes = (off + 15u) & ~15u;
 }
 
@@ -99,10 +101,12 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     const int n_fixed = SREC ? 0 : a.n_fixed;                    // scalar records: the host offers them without fixed links only
     const unsigned act_row = SREC ? row : (unsigned)b * (unsigned)a.act_stride;
     const bool cfg_export_actions = a.rb_out != nullptr;
-    const bool capacity_reward = a.reward_fn == 1;               // SystemCapacity (env-wide mean); else Shannon (per link)
+    const bool capacity_reward = a.reward_fn == 1;               // SystemCapacity (env-wide mean) | 2: Shannon (per link) | 3: CueSinrShannon (per
+    const bool shannon_reward = a.reward_fn == 2;                // link, looks at the other members of the RB: one link per thread only)
+    const bool cue_sinr_reward = LPT == 1 && a.reward_fn == 3;
     const unsigned EMPTY = (unsigned)N * 16u;                    // byte offset of the stand-in tuple link[N]
     const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
-    const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u, L_RED = a.lds.aux;
+    const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u, L_RED = a.lds.aux, L_LOW = a.lds.rx;
 
     RO_STAMP(0);
     // ---- prologue: the links' loads, issued before any LDS work or barrier (their latency overlaps pass 0)
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     }
 
     float caps[LPT], rates[LPT], sinrs[LPT], snrs[LPT];
+    float sh_kept = 0.0f;                                        // CueSinrShannon's value (one link per thread)
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
         const int i = link_of(u);
@@ -434,7 +439,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         const bool rule = capacity_reward && type != LINK_SIDELINK && cap <= a.reward_param;
         // ShannonRewardFunction (reward_fn.py:52-57) is per link: log2(1 + SINR), or -1 below the threshold.  (A plain 4-byte store
         // per link, in here: the value would otherwise stay live across the other link's evaluation - a 65th VGPR.)
-        if (!capacity_reward) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = sinr_db >= a.reward_param ? sh : -1.0f;
+        if (shannon_reward) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = sinr_db >= a.reward_param ? sh : -1.0f;
+        if (LPT == 1) sh_kept = sh;
         const bool nonfinite = MODE == PL_INV_SQUARE ? !(fabsf(sinr_db) <= 3.0e38f) : (dmin == 0 || !(fabsf(sinr_db) <= 3.0e38f));
         const bool huge = !(cap <= 3.0e7f);
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(rule | nonfinite | huge) != 0ull)) {
@@ -474,6 +480,41 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             if (huge && !PAD) lds_atomic_or(L_FLAGS + 4u, cap != cap ? 4 : 2);   // (padded: a float sum, which carries inf / NaN itself)
         }
         RO_STAMP(5 + u);
+    }
+
+    if (cue_sinr_reward) {
+        // ---- CueSinrShannonRewardFunction, reward_fn.py:65-78: -1 where another member of my RB is a non-D2D link whose SINR is below
+        // the threshold, else log2(1 + SINR).  Every link publishes that predicate about ITSELF; after one barrier a link reads it
+        // for the members of its RB's row (the stand-in's entry is 0), the pool where the row overflowed, every link where the RB is
+        // out of range - the search of pass 2 once more, with a 4-byte read per member instead of a pair evaluation.
+        const int i = link_of(0);
+        const unsigned my_off = (unsigned)i << 4;
+        const int type = (in[0].ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
+        lds_put<int>(L_LOW + ((unsigned)i << 2), (type != LINK_SIDELINK) & (sinrs[0] < a.reward_param) ? 1 : 0);
+        if (tid == 0) lds_put<int>(L_LOW + ((unsigned)N << 2), 0);
+        __syncthreads();
+        int low = 0;
+        if (oor[0]) {
+            COLD_LOOP
+            for (int k = 0; k < N; ++k)
+                low |= (k != i) & (__float_as_int(lds_get<f32x4>(L_LINK + ((unsigned)k << 4)).w) == rb[0]) ? lds_get<int>(L_LOW + ((unsigned)k << 2)) : 0;
+        } else {
+            const u32x4 ml = lds_get<u32x4>(L_SLOTS + (unsigned)rb[0] * 16u);
+            const unsigned o[RO_SLOTS] = {ml.x & 0xFFFFu, ml.x >> 16, ml.y & 0xFFFFu, ml.y >> 16, ml.z & 0xFFFFu, ml.z >> 16, ml.w & 0xFFFFu, ml.w >> 16};
+#pragma unroll
+            for (int k = 0; k < RO_SLOTS; ++k) { const int f = lds_get<int>(L_LOW + (o[k] >> 2)); low |= o[k] != my_off ? f : 0; }
+            if (__builtin_amdgcn_ballot_w64(o[7] != EMPTY) != 0ull) {
+                if (o[7] != EMPTY && lds_get<unsigned>(L_CNT + (unsigned)rb[0] * 4u) > (unsigned)RO_SLOTS) {
+                    const unsigned pc = min(lds_get<unsigned>(L_FLAGS + 12u), (unsigned)N);
+                    COLD_LOOP
+                    for (unsigned p = 0; p < pc; ++p) {
+                        const u32x2 e = lds_get<u32x2>(L_POOL + p * 8u);
+                        if (e.x == (unsigned)rb[0] && e.y != (unsigned)i) low |= lds_get<int>(L_LOW + (e.y << 2));
+                    }
+                }
+            }
+        }
+        *at(a.reward, fresh((row + (unsigned)i) * 4u)) = low ? -1.0f : sh_kept;
     }
 
     // ---- results: the thread's LPT links are adjacent elements of every plane and adjacent rows of the table
