@@ -1,46 +1,49 @@
 // Rollout kernel for gfx950 (MI355X): the step of a learner's rollout - raw agent actions for every link (or all but a prefix with
-// fixed actions: traffic-model CUEs), any of the three rewards, one env per workgroup of N / LPT threads, sparse RB occupancy (N <= 4 R) - with a STRAIGHT-LINE hot path.
+// fixed actions: traffic-model CUEs), any of the three rewards, one env per workgroup of N / LPT threads, sparse RB occupancy
+// (N <= 4 R) - with a STRAIGHT-LINE hot path.
 //
 // Reference path (file:line under /root/reference/src/gym_d2d): the same as csrc/d2d_step.hip -
 //   D2DEnv._decode_action envs/d2d_env.py:93-101, Actions.get_actions_by_rb actions.py:27-31,
 //   Simulator._calculate_sinrs / _snrs / _rates / _network_capacity simulator.py:89-154,
-//   SystemCapacityRewardFunction envs/reward_fn.py:27-44, ShannonRewardFunction :47-57, CueSinrShannonRewardFunction :60-78, LinearObsFunction's base table
-//   envs/obs_fn.py:55-61.
+//   SystemCapacityRewardFunction envs/reward_fn.py:27-44, ShannonRewardFunction :47-57, CueSinrShannonRewardFunction :60-78,
+//   LinearObsFunction's base table envs/obs_fn.py:55-61.
 //
-// Why a kernel of its own (round 5): at 36 - 64 bytes per link the step is paced by the instructions a CU can issue, of every
-// kind (profiles/r4_elasticity_step_kernel.json; about one wave-instruction per cycle and CU), not by HBM.  The generic
+// Why a kernel of its own (round 5): at 36 - 64 bytes per link the step is paced by the instructions its waves issue, of every
+// kind (a wave gets one in every 7.5 cycles or so: profiles/r5_issue_rates.txt), not by HBM.  The generic
 // kernel's member-list walk spent 70 of its 246 VALU per wave on taking the own entry out of the RB's list, sorting the rest
 // and clamping the indices, and ~40 of its 102 SALU on exec-mask bookkeeping around per-lane rarities.  This kernel
 //   * keeps every per-lane rarity behind wave-uniform ballot branches that the common wave never enters: an action beyond the
 //     multiply-high decode's bound (refresh_tables keeps it below R * P, so inside it the quotient is exact AND a valid RB) is
 //     decoded by division; a link whose RB lies outside [0, R) enters no list and sweeps all pairs; the ninth and later links
 //     of an RB go to a per-env OVERFLOW POOL of (rb, link) pairs that only the members of such an RB ever scan - no
-//     membership masks, no workgroup-wide fallback, 15 KB of LDS per env instead of 37 KB;
-//   * stores the list entries as LDS BYTE OFFSETS of the members' tuples (u16, link * 16; empty = N * 16, the zero-power
-//     stand-in tuple), so an entry is an address: no clamp, no shift;
+//     membership masks, no workgroup-wide fallback, 17 KB of LDS per env instead of 37 KB;
+//   * stores the list entries as LDS BYTE OFFSETS of the members' tuples (u16, link * 16; empty = N * 16, a stand-in tuple
+//     of power -0.0), so an entry is an address: no clamp, no shift;
 //   * does NOT sort and does NOT take the own entry out: the interference sum starts at minus the own term and adds all
 //     eight slots in arrival order.  Every term is a float (24 bits) added in double (53 bits): while the largest and the
 //     smallest non-zero term of a lane are less than 2^25 apart, every partial sum of the at most nine values is exact,
 //     hence independent of the order and equal - bit for bit - to the ascending-order sum of the mask walk and the
-//     all-pairs sweep.  The two extremes are tracked with one v_max3 / v_min3 pair per two terms; a lane outside the
-//     window (1e-6 of lanes without, 5e-5 with the own term at BASELINE config 3 geometry) re-does its sum in sorted order;
+//     all-pairs sweep.  The two extremes are tracked with one v_max3_i32 / v_min3_u32 pair per two terms (the stand-in's
+//     term, -0.0, is neutral for both); a lane outside the window (5e-5 of lanes at BASELINE config 3 geometry) re-does its
+//     sum in sorted order;
 //   * LPT = 2: a thread carries two ADJACENT links (2t and 2t + 1), so every per-WAVE instruction - the scalar record load, barriers,
 //     ballots, the wave reduction, the ticket - is paid once per 128 links instead of once per 64, half as many waves are launched,
 //     the thread's two actions are one 8-byte load and its two results one 8-byte element of every plane.  The capacity sum
 //     keeps the bits of the one-link kernels: their wave sum is a balanced tree over adjacent links, whose first level here is the
 //     lane's own pair (wave_sum_halves);
 //   * with two links per thread the TABLE ROWS (24 bytes per link) leave through LDS, so that every store instruction writes
-//     1024 contiguous bytes (see the results section: 26.7 -> 24.5 us in the table mode).
-//   * a link count that is no multiple of 64 (OPT_PAD) is padded to the next one with threads that SHADOW the last link (see the top of
-//     the kernel), and its reward is reduced as the generic kernels reduce it for such shapes;
+//     1024 contiguous bytes (see the results section: 26.7 -> 24.5 us in the table mode);
+//   * a link count that is no multiple of 64 (OPT_PAD) is padded to the next one with threads that SHADOW the last link (see the
+//     top of the kernel), and its reward is reduced as the generic kernels reduce it for such shapes.
 // Same arithmetic as step_kernel everywhere else (tests/test_gpu_step_variants.py holds the two bit-identical).
 //
 // Worst case: an env whose actions pile more than eight links on one RB costs its members a scan of the pool (<= N entries);
 // a lane whose terms then fall outside the exactness window (25 bits at 9 - 15 members ... 18 at 2047) takes them in ascending
 // order by selection (up to 32 members) or by one all-pairs sweep - bounded by N pair evaluations per link, what the
 // reference's own loop does (simulator.py:95-101).  (A first version swept at an 18-bit window whatever the member count: a
-// few hundred lanes per launch at BASELINE config 3, each outliving the launch - 47 us median against a 16 us minimum.)  A workload that lives there
-// (N > 4 R on average) is not given this kernel (run_step), and D2D_TUNE_STEP_WALK = 0 keeps the mask walk for any other.
+// few hundred lanes per launch at BASELINE config 3, each outliving the launch - 47 us median against a 16 us minimum.)  A
+// workload that lives there (N > 4 R on average) is not given this kernel (run_step), and D2D_TUNE_STEP_WALK = 0 keeps the mask
+// walk for any other.
 #include <cstring>
 
 #include "d2d_step_device.h"
@@ -48,7 +51,7 @@
 namespace d2d {
 
 #define RO_SLOTS 8
-// diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py --kernel rollout)
+// diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py)
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
 #define RO_STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0)                                                            \
         a.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -58,7 +61,8 @@ namespace d2d {
 #define RO_ST(ptr, val) do { if (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 
 // LDS of one env (byte offsets; StepLds): 0 sum (u64) ... 60 dump (u16) | 64 flags[4]: env flags, reward bits, ticket, pool count
-// | 80 link[N + 1] tuples | expo[N + 1] (power law) | slots[R + 1] (8 x u16) | cnt[R + 1] | pool[N] (rb, link)
+// | 80 link[N + 1] tuples | expo[N + 1] (power law) | slots[R + 1] (8 x u16) | cnt[R + 1] | pool[N] (rb, link) | 16 wave sums
+// (padded link counts) | low[N + 1] (CueSinrShannon).  With two links per thread the region from 80 on becomes the env's table image.
 void rollout_lds_layout(int N, int R, int mode, int reward_fn, StepLds* out) {
     std::memset(out, 0, sizeof(*out));
     unsigned off = LDS_HEAD_BYTES + ((unsigned)N + 1u) * 16u;
