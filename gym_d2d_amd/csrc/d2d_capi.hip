@@ -455,10 +455,11 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // than four links per RB on average a ninth link on some RB is the rule, the list build is wasted and the workgroup
     // sweeps all pairs anyway (N > 8 R: by pigeonhole), so those shapes go straight to the sweep
     const bool lists_can_help = (long long)N <= 4ll * h->cfg.num_rbs;
-    // The rollout kernel (d2d_rollout.hip) serves: raw agent actions for every link, SystemCapacity, one env per workgroup (N a
-    // multiple of 64, no fused expansion), a power-law path loss.  Round 5: it is the faster one in every obs mode (same box,
-    // 4096 x 512, r4 HEAD -> rollout: obs-less 21.3 -> 19.3 us, compact table 27.7 -> 25.8, with the decoded planes 28.3 -> 27.3;
-    // profiles/r5_ab_rollout_kernel.jsonl), so wherever it applies the lists are the default.
+    // The rollout kernel (d2d_rollout.hip) serves: raw agent actions for every link or for all but a prefix with fixed actions, any of
+    // the three rewards, one env per workgroup (64 ... 1024 links: a multiple of 64, or more than 128 padded to the next one; no
+    // fused expansion), a power-law path loss.  Round 5: it is the faster one in every obs mode (same box, 4096 x 512, r4 HEAD ->
+    // rollout: obs-less 21.3 -> 19.3 us, compact table 27.7 -> 25.8, with the decoded planes 28.3 -> 27.3,
+    // profiles/r5_ab_rollout_kernel.jsonl; further since), so wherever it applies the lists are the default.
     const bool will_fuse = h->obs_mode == D2D_OBS_LINEAR && !h->obs_f64 && (h->tune_step_fuse >= 0 ? h->tune_step_fuse != 0 : N <= 128);
     const bool rollout_cfg = action_mode == 0 && (h->n_fixed == 0 || (h->n_fixed < N && h->col_mode == 0)) && h->bucketing &&   // fixed links: a prefix
                              (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON ||
