@@ -456,7 +456,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // sweeps all pairs anyway (N > 8 R: by pigeonhole), so those shapes go straight to the sweep
     const bool lists_can_help = (long long)N <= 4ll * h->cfg.num_rbs;
     // The rollout kernel (d2d_rollout.hip) serves: raw agent actions for every link or for all but a prefix with fixed actions, any of
-    // the three rewards, one env per workgroup (64 ... 1024 links: a multiple of 64, or more than 128 padded to the next one; no
+    // the three rewards, one env per workgroup (64 ... 1024 links: a multiple of 64, or padded to the next one; no
     // fused expansion), a power-law path loss.  Round 5: it is the faster one in every obs mode (same box, 4096 x 512, r4 HEAD ->
     // rollout: obs-less 21.3 -> 19.3 us, compact table 27.7 -> 25.8, with the decoded planes 28.3 -> 27.3,
     // profiles/r5_ab_rollout_kernel.jsonl; further since), so wherever it applies the lists are the default.
@@ -466,7 +466,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
                               h->reward_fn == D2D_REWARD_CUE_SINR_SHANNON) &&
                              !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && (h->tune_step_ablate & ~8192) == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
-                             (N % 64 == 0 || N > 128) && N <= 1024;      // (no multiple of 64: padded, above the sizes whose envs share a workgroup)
+                             (N % 64 == 0 || N > 64) && N <= 1024;       // (no multiple of 64: padded; measured from 80 links up)
     const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE || rollout_cfg);
     s.walk = h->tune_step_walk >= 0 ? h->tune_step_walk : (lists_pay ? 2 : 0);
 
