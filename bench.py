@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: D2DEnv.step for a batch of environments on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stress|default|plugin] [--obs linear|table|none]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stress|default|plugin|hata] [--obs linear|table|none]
 
 A "step" is one pass of the fused path over the whole batch: action decode -> SINR / SNR / rate / capacity -> reward
 -> observation table -> LinearObs expansion (reference semantics: obs materialised as [B, N, 6N] in HBM), with fresh
@@ -53,6 +53,10 @@ WORKLOADS = {
     # a custom array ObsFunction (own link only); same sizes as 'stress'
     'plugin': dict(name='4096 envs x (256 CUE + 256 DUE pairs, 256 RB), FreeSpacePathLoss + OwnLinkObsFunction plugins',
                    envs=4096, rbs=256, cues=256, dues=256, plugin=True),
+    # rows a5 / a5'' at the stress sizes: an exponent other than 2 (COST-Hata, path_loss.py:90-123) -> the power-law kernels, which
+    # no BASELINE configuration runs (the lowest HBM fraction in the repo had no evidence of its own)
+    'hata': dict(name='4096 envs x (256 CUE + 256 DUE pairs, 256 RB), CostHataPathLoss (power-law kernel)',
+                 envs=4096, rbs=256, cues=256, dues=256, hata=True),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -352,7 +356,7 @@ class Session:
     """One workload on this rank's GPU: the env, its pre-generated actions and the timing loops."""
 
     def __init__(self, torch, args, key, obs, dev, rank, local, steps, warmup, *, envs=0, cue_mode='', tune='', stub=False,
-                 export=True, action_pool=0, placement_trials=0, f64=False):
+                 export=True, action_pool=0, placement_trials=0, f64=False, reward_per_env=None):
         self.torch, self.args, self.key, self.obs, self.dev, self.rank, self.stub = torch, args, key, obs, dev, rank, stub
         self.export = export
         self.f64 = bool(f64) and obs == 'linear'
@@ -380,9 +384,12 @@ class Session:
             if w.get('plugin'):
                 from gym_d2d_amd.path_loss import FreeSpacePathLoss
                 cfg['path_loss_model'] = FreeSpacePathLoss
+            if w.get('hata'):
+                from gym_d2d_amd.path_loss import CostHataPathLoss
+                cfg['path_loss_model'] = CostHataPathLoss
             if self.f64:
                 cfg['obs_dtype'] = 'float64'
-            self.reward_per_env = bool(getattr(args, 'reward_per_env', False)) and obs != 'linear'
+            self.reward_per_env = bool(getattr(args, 'reward_per_env', False) if reward_per_env is None else reward_per_env) and obs != 'linear'
             self.env = VecD2DEnv(cfg, num_envs=b, first_env=rank * b, cue_actions=self.cue_mode, export_actions=export,
                                  reward_per_env=self.reward_per_env, placement_trials=placement_trials)
             self.h = h = self.env.simulator.handle
@@ -478,6 +485,12 @@ class Session:
             obs_ms, obs_n = 0.0, 0
             per_group = sorted(e0.elapsed_time(e1) / c for e0, e1, c in pairs)
             step_med, obs_med = (per_group[len(per_group) // 2] if per_group else 0.0), 0.0
+            if per_group:
+                q = lambda f: per_group[min(len(per_group) - 1, int(f * len(per_group)))] * 1e3
+                self.launch_distribution_us = {'min': q(0.0), 'p10': q(0.1), 'median': q(0.5), 'p90': q(0.9), 'max': per_group[-1] * 1e3,
+                                               'groups': len(per_group), 'launches_per_group': GROUP,
+                                               'what': f'average launch duration of each group of {GROUP} back-to-back launches (one HIP-event pair per '
+                                                       'group: a pair around ONE launch adds 3 - 6 us to what it measures), over the timed steps'}
         return {'dt': dt, 'step_ms': step_ms, 'step_n': step_n, 'obs_ms': obs_ms, 'obs_n': obs_n, 'step_median_ms': step_med, 'obs_median_ms': obs_med}
 
     def roofline(self, t):
@@ -508,6 +521,12 @@ class Session:
                                 else f'HIP events around groups of {GROUP} back-to-back launches (one kernel per step) on the '
                                      'library stream, in a second pass over the same steps; the timed region itself runs '
                                      'without events; median = the median group')})
+        if not fused and not (self.obs == 'linear' and t['obs_n']) and self.obs == 'table' and self.current_export():
+            # SURVEY.md 8(d) prices the compact-table step at 40 + 24 = 64 bytes per link; this configuration also writes the decoded
+            # (rb, pwr) planes (72): the same launch on the 64-byte accounting, beside it
+            roof['frac_on_64B_accounting'] = (b * n * 64.0 / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else None
+        if getattr(self, 'launch_distribution_us', None) and not self.events_in_timed:
+            roof['launch_distribution_us'] = self.launch_distribution_us
         if not self.stub:
             attach_traffic(roof, self.key, self.obs + ('_f64' if self.f64 else '') + ('_per_env_reward' if getattr(self, 'reward_per_env', False) else ''),
                            bool(self.args.envs), self.current_export())
@@ -520,7 +539,7 @@ class Session:
         w = self.w
         return {'workload': w['name'], 'envs_per_gpu': self.b, 'links_per_env': self.n, 'obs_mode': self.obs,
                 'reward_fn': 'SystemCapacity',
-                'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else 'LogDistance(ple=2)',
+                'path_loss': 'FreeSpacePathLoss (plugin class)' if w.get('plugin') else ('CostHataPathLoss (suburban; per-device exponents 3.5 - 4.4)' if w.get('hata') else 'LogDistance(ple=2)'),
                 'actions': 'fresh i.i.d. per step (pre-generated in HBM)',
                 'api': 'C-ABI handle (d2d_step)' if (self.stub or self.raw_handle) else 'VecD2DEnv.step(actions) -> (obs, rewards, dones, info), the public batched API',
                 'decoded_rb_pwr_export': 'on' if self.export else 'off (d2d_set_export_actions(0))',
@@ -765,7 +784,12 @@ def worker(args):
         ow = extras.get('other_workloads', {})
         flat = {'frac_config2': _frac(ow, 'default', 'roofline'), 'us_per_step_config2': (ow.get('default') or {}).get('ms_per_step'),
                 'frac_config2_with_placement_trials': (ow.get('default') or {}).get('with_placement_trials_24', {}).get('frac'),
-                'frac_config4': _frac(ow, 'plugin', 'roofline'), 'frac_obs_float64': _frac(ow, 'stress_float64_obs', 'roofline'),
+                'frac_config4': _frac(ow, 'plugin', 'roofline'),
+                'frac_config4_on_64B': ((ow.get('plugin') or {}).get('roofline') or {}).get('frac_on_64B_accounting'),
+                'frac_power_law_obsless': _frac(ow, 'power_law_obsless', 'roofline'),
+                'us_config2_launch_min_median_p90': [((ow.get('default') or {}).get('roofline', {}).get('launch_distribution_us') or {}).get(k) for k in ('min', 'median', 'p90')]
+                if ((ow.get('default') or {}).get('roofline', {}).get('launch_distribution_us')) else None,
+                'frac_obs_float64': _frac(ow, 'stress_float64_obs', 'roofline'),
                 'frac_table_no_export': _frac(core or {}, 'roofline'), 'frac_table_with_export': _frac(core or {}, 'with_decoded_rb_pwr_export', 'roofline'),
                 'frac_obsless': _frac(core or {}, 'planes_only', 'roofline'),
                 'us_step_kernel_obsless': ((core or {}).get('planes_only', {}).get('roofline', {}) or {}).get('avg_launch_ms'),
@@ -880,6 +904,13 @@ def n1_extras(torch, args, dev, local, fence):
     # profiles/r4_clock_state_default.jsonl) - a 220-step run measured the ramp, not the kernel
     s = Session(torch, args, 'default', 'linear', dev, 0, local, 2000, 2000, action_pool=256)
     out['other_workloads']['default'] = summarise(s, s.timed(fence), 2000)          # a plain VecD2DEnv(cfg, 1024): no placement trials
+    # which lottery ticket this box / allocation drew (the 0.53 <-> 0.61 spread is where the 61 MB obs block sits
+    # physically - reproducible per allocation, predicted by nothing observable, profiles/NEGATIVE_RESULTS.md "Config 2")
+    med = (out['other_workloads']['default']['roofline'].get('launch_distribution_us') or {}).get('median')
+    if med:
+        out['other_workloads']['default']['roofline']['placement_class'] = (
+            ('fast' if med <= 13.5 else ('middle' if med < 14.5 else 'slow')) + f' (median group {med:.2f} us; classes seen on this pool: '
+            'about 13.2 / 13.9 / 15.1 us, profiles/r4_obs_block_placement_candidates.jsonl)')
     try:                                                  # what a pure fill of about the same size reaches on this box (61 MB of obs per step)
         small, _ = write_probe.write_variants(64 << 20, 20, local)
         out['other_workloads']['default']['roofline']['box_ceiling_GBs_64MiB_bursts'] = small
@@ -906,6 +937,15 @@ def n1_extras(torch, args, dev, local, fence):
     out['other_workloads']['plugin'] = summarise(s, s.timed(fence), 1000)
     out['vec_env_step_ms']['stress sizes, compact obs (OwnLinkObsFunction)'] = s.vec_env_step_ms()
     s.close()
+    # an exponent other than 2 (COST-Hata: rows a5, a5''): the power-law rollout kernel in the obs-less learner mode
+    try:
+        s = Session(torch, args, 'hata', 'none', dev, 0, local, 1000, 1000, action_pool=64, export=False, reward_per_env=True)
+        try:
+            out['other_workloads']['power_law_obsless'] = summarise(s, s.timed(fence), 1000)
+        finally:
+            s.close()
+    except Exception as exc:                              # pragma: no cover
+        out['other_workloads']['power_law_obsless'] = {'error': repr(exc)}
     # the stress workload as EPISODES: positions redrawn on the device every 10 steps (d2d_env.py:16,45-52), 3 episodes
     s = Session(torch, args, 'stress', 'linear', dev, 0, local, 30, 10)
     e = summarise(s, s.timed(fence, None, True), 30)

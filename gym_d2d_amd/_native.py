@@ -9,7 +9,7 @@ from typing import Optional
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libd2d_hip.so'
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LINKS = 2048
 
 # d2d_status
@@ -78,6 +78,7 @@ SIGNATURES = {
     'd2d_set_path_loss_power_law': (C.c_int, [_P, _I, _DP, _DP, _DP]),
     'd2d_set_path_loss_table': (C.c_int, [_P, _DP, _I]),
     'd2d_set_path_loss_link_table': (C.c_int, [_P, _DP, _I, _I]),
+    'd2d_set_path_loss_link_table_dev': (C.c_int, [_P, _P, _I, _I, _I]),
     'd2d_set_path_loss_shadowing': (C.c_int, [_P, _I, _DP, _DP, _DP, C.c_double, C.c_double, C.c_uint64]),
     'd2d_set_links': (C.c_int, [_P, _I, _IP, _IP, _IP]),
     'd2d_set_fixed_actions': (C.c_int, [_P, _I, _IP, _IP, _IP]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     'd2d_upload': (C.c_int, [_P, _I, _P, C.c_size_t, C.c_size_t]),
     'd2d_download': (C.c_int, [_P, _I, _P, C.c_size_t, C.c_size_t]),
     'd2d_set_positions': (C.c_int, [_P, _FP, _FP, _I, _I]),
+    'd2d_set_positions_f64': (C.c_int, [_P, _DP, _DP, _I, _I]),
     'd2d_reset_positions': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), _FP]),
     'd2d_set_env_offset': (C.c_int, [_P, C.c_uint64]),
     'd2d_step': (C.c_int, [_P, _P]),
@@ -208,6 +210,10 @@ class Handle:
             raise ValueError(f'link path-loss table must be [N,N] or [{self.num_envs},N,N], got {t.shape}')
         _check(self._lib.d2d_set_path_loss_link_table(self._h, _dptr(t), n, int(t.ndim == 3)))
 
+    def set_path_loss_link_table_dev(self, dev_ptr: int, dtype: int, n_links: int, per_env: bool) -> None:
+        """The link table from DEVICE memory (float32 / float64 dB, [N,N] or [B,N,N]): converted to gains by a kernel, no host copy."""
+        _check(self._lib.d2d_set_path_loss_link_table_dev(self._h, _P(dev_ptr), dtype, n_links, int(per_env)))
+
     def set_links(self, tx_dev, rx_dev, link_type) -> None:
         a = [np.ascontiguousarray(c, dtype=np.int32) for c in (tx_dev, rx_dev, link_type)]
         n = len(a[0])
@@ -291,10 +297,17 @@ class Handle:
         return out
 
     def set_positions(self, x: np.ndarray, y: np.ndarray, env_begin: int = 0) -> None:
-        x = np.ascontiguousarray(x, dtype=np.float32); y = np.ascontiguousarray(y, dtype=np.float32)
+        """x, y [envs, D].  float64 arrays go through d2d_set_positions_f64 - the reference's own precision (position.py:7-12), kept
+        as (hi, lo) float32 pairs on the device; anything else is uploaded as float32."""
+        exact = getattr(x, 'dtype', None) == np.float64 and getattr(y, 'dtype', None) == np.float64
+        dtype = np.float64 if exact else np.float32
+        x = np.ascontiguousarray(x, dtype=dtype); y = np.ascontiguousarray(y, dtype=dtype)
         if x.shape != y.shape or x.ndim != 2 or x.shape[1] != self.num_devices:
             raise ValueError(f'positions must be [envs, {self.num_devices}]')
-        _check(self._lib.d2d_set_positions(self._h, x.ctypes.data_as(_FP), y.ctypes.data_as(_FP), env_begin, x.shape[0]))
+        if exact:
+            _check(self._lib.d2d_set_positions_f64(self._h, _dptr(x), _dptr(y), env_begin, x.shape[0]))
+        else:
+            _check(self._lib.d2d_set_positions(self._h, x.ctypes.data_as(_FP), y.ctypes.data_as(_FP), env_begin, x.shape[0]))
 
     def reset_positions(self, seed: int, episode: int = 0, fixed_mask=None, fixed_xy=None) -> None:
         m = xy = None

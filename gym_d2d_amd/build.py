@@ -22,7 +22,7 @@ PROBE_PATH = LIB_DIR / 'libd2d_probe.so'
 INCLUDE = PKG.parent / 'include'
 ARCH = 'gfx950'
 
-SOURCES = ['d2d_step.hip', 'd2d_rollout.hip', 'd2d_obs.hip', 'd2d_reset.hip', 'd2d_capi.hip']
+SOURCES = ['d2d_step.hip', 'd2d_rollout.hip', 'd2d_obs.hip', 'd2d_reset.hip', 'd2d_gain.hip', 'd2d_capi.hip']
 PROBE_SOURCES = ['d2d_probe.hip']
 HEADERS = [CSRC / 'd2d_internal.h', CSRC / 'd2d_step_device.h', CSRC / 'd2d_store.h', INCLUDE / 'd2d_hip.h', INCLUDE / 'd2d_hip_diag.h']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-unused-value',

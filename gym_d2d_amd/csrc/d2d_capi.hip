@@ -80,6 +80,10 @@ struct d2d_handle {
     unsigned* side_words = nullptr; // [ceil(Nmax / 32)] sidelink membership bits, rebuilt with the records
     float4* lpos = nullptr;         // [B, Nmax] per-link (tx_x, tx_y, rx_x, rx_y), see refresh_link_positions
     bool lpos_dirty = true;
+    // exact positions (d2d_set_positions_f64): coordinate = hi + lo; hi lives in POS_X / POS_Y (and lpos), the low parts here
+    float* pos_lo = nullptr;        // [2][B, D]: x low parts, then y low parts (allocated by the first float64 upload)
+    float4* lpos_lo = nullptr;      // [B, Nmax] low parts of the per-link rows
+    bool have_lo = false;           // some coordinate has a non-zero low part: the step runs the OPT_XPOS kernels
     unsigned long long* dbg = nullptr;   // diagnostic builds only
     bool rec_uniform = false;       // records identical within every aligned group of 64 links (refresh_tables)
     bool rec_uniform128 = false;    // ... and within every aligned group of 128: the rollout kernel's two links per thread
@@ -301,7 +305,10 @@ int refresh_tables(d2d_handle* h) {
 // reset / set_positions / set_links - simulator.py:61-75 is the only place the reference moves devices).
 int refresh_link_positions(d2d_handle* h, const float* px, const float* py) {
     if (!h->lpos_dirty) return D2D_OK;
-    HIP_TRY(d2d::launch_link_positions(px, py, reinterpret_cast<const int4*>(h->rec), h->B, h->N, h->D, h->lpos, h->stream));
+    const size_t bd = (size_t)h->B * h->D;
+    if (h->have_lo && !h->lpos_lo) HIP_TRY(hipMalloc(&h->lpos_lo, (size_t)h->B * h->Nmax * 16));
+    HIP_TRY(d2d::launch_link_positions(px, py, h->have_lo ? h->pos_lo : nullptr, h->have_lo ? h->pos_lo + bd : nullptr,
+                                       reinterpret_cast<const int4*>(h->rec), h->B, h->N, h->D, h->lpos, h->have_lo ? h->lpos_lo : nullptr, h->stream));
     h->lpos_dirty = false;
     return D2D_OK;
 }
@@ -455,6 +462,8 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // than four links per RB on average a ninth link on some RB is the rule, the list build is wasted and the workgroup
     // sweeps all pairs anyway (N > 8 R: by pigeonhole), so those shapes go straight to the sweep
     const bool lists_can_help = (long long)N <= 4ll * h->cfg.num_rbs;
+    // float64 positions uploaded as (hi, lo) pairs (d2d_set_positions_f64) with a non-zero low part somewhere: the OPT_XPOS kernels
+    const int xpos = h->have_lo ? 1 : 0;
     // The rollout kernel (d2d_rollout.hip) serves: raw agent actions for every link or for all but a prefix with fixed actions, any of
     // the three rewards, one env per workgroup (64 ... 1024 links: a multiple of 64, or padded to the next one; no
     // fused expansion), a power-law path loss.  Round 5: it is the faster one in every obs mode (same box, 4096 x 512, r4 HEAD ->
@@ -503,14 +512,14 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     int W = 0;
     if (h->bucketing && lpt > 0 && N <= 1024) {
         W = (N + 31) / 32;
-        if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) W = 0;
+        if (d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, xpos) > 96 * 1024) W = 0;
     }
     // masks that do not fit (thousands of RBs): the lists are 20 bytes per RB instead of 4 per RB and 32 links - take them when
     // nobody chose a search variant
     if (W == 0 && !lists && lists_can_help && h->tune_step_walk < 0 && h->bucketing && lpt > 0 && s.reward_fn != D2D_REWARD_CUE_SINR_SHANNON) { lists = 1; s.walk = 2; }
-    if (lists && d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists) > 96 * 1024) { lists = 0; s.walk = 0; }
+    if (lists && d2d::step_lds_bytes_per_env(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, xpos) > 96 * 1024) { lists = 0; s.walk = 0; }
     s.lpt = lpt;
-    d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, &s.lds);
+    d2d::step_lds_layout(N, s.R, W, fuse, lpt, s.reward_fn, (int)h->mode, lists, xpos, &s.lds);
     // The rollout kernel (d2d_rollout.hip): raw agent actions for every link, SystemCapacity, one env per workgroup, a power-law
     // path loss, member lists wanted.  Its own LDS layout: no masks, 17 KB per env at 512 links on 256 RBs.
     if (rollout_wanted) {
@@ -527,9 +536,10 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
         if (rl == 2 && !h->rec_uniform128) s.rec_uniform = false;     // forced by the tuning key on other records: per-lane records
         if (h->n_fixed > 0) { s.rec_uniform = false; rl = 1; }         // fixed actions live in per-link records: one link per thread
         if (s.reward_fn == D2D_REWARD_CUE_SINR_SHANNON) rl = 1;        // its second look at the RB's members: one link per thread
+        if (xpos) rl = 1;                                              // exact positions: one link per thread (a fourth 16-byte row per link)
         {
             d2d::StepLds rlds;
-            d2d::rollout_lds_layout(N, s.R, (int)h->mode, s.reward_fn, &rlds);
+            d2d::rollout_lds_layout(N, s.R, (int)h->mode, s.reward_fn, xpos, &rlds);
             if (rlds.env_bytes <= 64 * 1024) {
                 s.rollout = 1; s.lds = rlds;
                 lpt = rl; tpe = ((N / rl + 63) / 64) * 64; W = 0; s.lpt = lpt;
@@ -617,6 +627,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     s.rec_h = h->rec_h;
     s.rec_grp = h->rec_grp;
     s.lpos = h->lpos;
+    s.lpos_lo = xpos ? h->lpos_lo : nullptr;
     s.act_cols = h->act_cols;
     s.side_words = h->side_words;
     s.gain_table = h->gain_table;
@@ -739,7 +750,7 @@ int d2d_create(const d2d_config* cfg, d2d_handle** out) try {
         return fail(D2D_ERR_UNSUPPORTED, std::string("libd2d_hip is built for gfx950 only, found ") + prop.gcnArchName);
 
     d2d_handle* h = new (std::nothrow) d2d_handle();
-    if (!h) return fail(D2D_ERR_INVALID, "out of host memory");
+    if (!h) return fail(D2D_ERR_NO_MEMORY, "out of host memory");
     h->cfg = *cfg;
     h->B = cfg->num_envs;
     h->D = 1 + cfg->num_cues + 2 * cfg->num_due_pairs;
@@ -784,6 +795,8 @@ int d2d_destroy(d2d_handle* h) try {
     if (h->rec_h) hipFree(h->rec_h);
     if (h->rec_grp) hipFree(h->rec_grp);
     if (h->lpos) hipFree(h->lpos);
+    if (h->lpos_lo) hipFree(h->lpos_lo);
+    if (h->pos_lo) hipFree(h->pos_lo);
     if (h->dbg) hipFree(h->dbg);
     if (h->act_cols) hipFree(h->act_cols);
     if (h->side_words) hipFree(h->side_words);
@@ -860,14 +873,29 @@ namespace {
 // the 1e-5 bar) of `elems` table entries into the handle's device table, through two pinned staging blocks of at most 1 Mi
 // floats each: the host never holds a second copy of the caller's table (9.7 GB for a per-env table at BASELINE config 3
 // sizes before round 5), and the conversion of one chunk overlaps the copy of the other.
-int upload_gain_table(d2d_handle* h, const double* pl_db, size_t elems) {
+// From the first byte a new table overwrites until it is complete, the handle has NO table: a failed allocation or copy must not
+// leave PL_TABLE selected over a null or half-written one (the next step then fails with D2D_ERR_STATE instead of faulting).
+void gain_table_invalid(d2d_handle* h) {
+    if (h->mode == d2d::PL_TABLE) h->have_pl = false;
+    h->table_links = 0;
+    h->tables_dirty = true;
+}
+
+int reserve_gain_table(d2d_handle* h, size_t elems) {
     HIP_TRY(hipStreamSynchronize(h->stream));
+    gain_table_invalid(h);
     if (h->gain_elems < elems) {
         if (h->gain_table) HIP_TRY(hipFree(h->gain_table));
         h->gain_table = nullptr; h->gain_elems = 0;
         HIP_TRY(hipMalloc(&h->gain_table, elems * 4));
         h->gain_elems = elems;
     }
+    return D2D_OK;
+}
+
+int upload_gain_table(d2d_handle* h, const double* pl_db, size_t elems) {
+    int rc0 = reserve_gain_table(h, elems);
+    if (rc0) return rc0;
     const size_t chunk = std::min<size_t>(elems, (size_t)1 << 20);
     float* stage[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
@@ -905,6 +933,24 @@ int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env)
     if (rc) return rc;
     h->table_per_env = per_env ? 1 : 0;
     h->table_links = 0;
+    h->mode = d2d::PL_TABLE;
+    h->have_pl = true; h->tables_dirty = true;
+    return D2D_OK;
+} D2D_CATCH
+
+int d2d_set_path_loss_link_table_dev(d2d_handle* h, const void* pl_db_dev, int32_t dtype, int32_t n_links, int32_t per_env) try {
+    if (!h || !pl_db_dev) return fail(D2D_ERR_INVALID, "null argument");
+    if (dtype != D2D_F32 && dtype != D2D_F64) return fail(D2D_ERR_INVALID, "dtype must be D2D_F32 or D2D_F64");
+    USE_DEVICE(h);
+    if (!h->have_links) return fail(D2D_ERR_STATE, "d2d_set_links first: the table is indexed by its link list");
+    if (n_links != h->N || n_links < 1) return fail(D2D_ERR_INVALID, "n_links must be the length of the current link list (" + std::to_string(h->N) + ")");
+    const size_t elems = (size_t)n_links * n_links * (per_env ? (size_t)h->B : 1);
+    int rc = reserve_gain_table(h, elems);
+    if (rc) return rc;
+    HIP_TRY(d2d::launch_gain_from_db(pl_db_dev, dtype == D2D_F64, elems, h->gain_table, h->num_cus, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));                 // the caller's table may be freed when this returns
+    h->table_per_env = per_env ? 1 : 0;
+    h->table_links = n_links;
     h->mode = d2d::PL_TABLE;
     h->have_pl = true; h->tables_dirty = true;
     return D2D_OK;
@@ -976,6 +1022,7 @@ int d2d_set_fixed_actions(d2d_handle* h, int32_t n_fixed, const int32_t* link_id
 int d2d_positions_changed(d2d_handle* h) try {
     if (!h) return fail(D2D_ERR_INVALID, "null handle");
     h->lpos_dirty = true;
+    h->have_lo = false;            // whoever wrote POS_X / POS_Y wrote float32 coordinates
     return D2D_OK;
 } D2D_CATCH
 
@@ -1033,6 +1080,7 @@ extern "C" int d2d_debug_stamps(d2d_handle* h, void* host, size_t bytes) try {
     if (!h || !h->dbg) return fail(D2D_ERR_STATE, "no stamps: set D2D_TUNE_STEP_ABLATE bit 8192 and step first");
     USE_DEVICE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!host || bytes > (size_t)h->B * 16 * 16 * 8) return fail(D2D_ERR_INVALID, "stamps: at most B x 16 waves x 16 stamps x 8 bytes");
     HIP_TRY(hipMemcpy(host, h->dbg, bytes, hipMemcpyDeviceToHost));
     return D2D_OK;
 } D2D_CATCH
@@ -1154,6 +1202,7 @@ int d2d_bind_buffer(d2d_handle* h, int32_t which, void* dev_ptr, size_t bytes) t
     if (which == D2D_BUF_POS_X || which == D2D_BUF_POS_Y) {
         h->have_pos = h->buf[D2D_BUF_POS_X].ptr && h->buf[D2D_BUF_POS_Y].ptr;
         h->lpos_dirty = true;
+        h->have_lo = false;        // float32 coordinates from here on (d2d_set_positions_f64 raises it again behind its own uploads)
     }
     return D2D_OK;
 } D2D_CATCH
@@ -1172,6 +1221,7 @@ int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes,
     if (which == D2D_BUF_POS_X || which == D2D_BUF_POS_Y) {
         h->have_pos = h->buf[D2D_BUF_POS_X].ptr && h->buf[D2D_BUF_POS_Y].ptr;
         h->lpos_dirty = true;
+        h->have_lo = false;        // float32 coordinates from here on (d2d_set_positions_f64 raises it again behind its own uploads)
     }
     return D2D_OK;
 } D2D_CATCH
@@ -1198,9 +1248,57 @@ int d2d_set_positions(d2d_handle* h, const float* x, const float* y, int32_t env
     if (!h || !x || !y) return fail(D2D_ERR_INVALID, "null argument");
     if (env_begin < 0 || env_count < 0 || env_begin + env_count > h->B) return fail(D2D_ERR_INVALID, "env range out of bounds");
     const size_t off = (size_t)env_begin * h->D * 4, bytes = (size_t)env_count * h->D * 4;
+    const bool keep_lo = h->have_lo && env_count < h->B;     // other envs hold float64 positions: this range's low parts become zero
     int rc = d2d_upload(h, D2D_BUF_POS_X, x, bytes, off);
     if (rc) return rc;
-    return d2d_upload(h, D2D_BUF_POS_Y, y, bytes, off);
+    rc = d2d_upload(h, D2D_BUF_POS_Y, y, bytes, off);
+    if (rc) return rc;
+    if (keep_lo) {
+        USE_DEVICE(h);
+        const size_t bd = (size_t)h->B * h->D;
+        HIP_TRY(hipMemsetAsync(h->pos_lo + (size_t)env_begin * h->D, 0, bytes, h->stream));
+        HIP_TRY(hipMemsetAsync(h->pos_lo + bd + (size_t)env_begin * h->D, 0, bytes, h->stream));
+        h->have_lo = true;
+    }
+    return D2D_OK;
+} D2D_CATCH
+
+int d2d_set_positions_f64(d2d_handle* h, const double* x, const double* y, int32_t env_begin, int32_t env_count) try {
+    if (!h || !x || !y) return fail(D2D_ERR_INVALID, "null argument");
+    if (env_begin < 0 || env_count < 0 || env_begin + env_count > h->B) return fail(D2D_ERR_INVALID, "env range out of bounds");
+    USE_DEVICE(h);
+    // coordinate = hi + lo: hi the nearest float32 (what POS_X / POS_Y, the obs table and every float32 consumer see), lo the
+    // float32 nearest to the remainder - together 48 bits of the double
+    const size_t n = (size_t)env_count * h->D, bd = (size_t)h->B * h->D;
+    std::vector<float> hi(2 * n), lo(2 * n);
+    bool any_lo = false;
+    for (int c = 0; c < 2; ++c) {
+        const double* src = c ? y : x;
+        for (size_t k = 0; k < n; ++k) {
+            const float a = (float)src[k];
+            const float b = std::isfinite(a) ? (float)(src[k] - (double)a) : 0.0f;
+            hi[c * n + k] = a; lo[c * n + k] = b;
+            any_lo |= b != 0.0f;
+        }
+    }
+    const bool had_lo = h->have_lo;                         // (the float32 uploads below clear the flag)
+    const size_t off = (size_t)env_begin * h->D * 4;
+    int rc = d2d_upload(h, D2D_BUF_POS_X, hi.data(), n * 4, off);
+    if (rc) return rc;
+    rc = d2d_upload(h, D2D_BUF_POS_Y, hi.data() + n, n * 4, off);
+    if (rc) return rc;
+    const bool keep = had_lo && env_count < h->B;           // envs outside this range hold low parts of their own
+    if (!any_lo && !keep) return D2D_OK;                    // every coordinate is a float32 value: the float32 kernels serve it, same bits
+    if (!h->pos_lo) {
+        HIP_TRY(hipMalloc(&h->pos_lo, 2 * bd * 4));
+        HIP_TRY(hipMemsetAsync(h->pos_lo, 0, 2 * bd * 4, h->stream));
+    } else if (!had_lo) HIP_TRY(hipMemsetAsync(h->pos_lo, 0, 2 * bd * 4, h->stream));      // stale low parts of an earlier layout
+    HIP_TRY(hipMemcpyAsync(h->pos_lo + (size_t)env_begin * h->D, lo.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->pos_lo + bd + (size_t)env_begin * h->D, lo.data() + n, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));               // lo is a stack-lifetime host buffer
+    h->have_lo = true;
+    h->lpos_dirty = true;
+    return D2D_OK;
 } D2D_CATCH
 
 int d2d_set_env_offset(d2d_handle* h, uint64_t first_env) try {
@@ -1239,6 +1337,7 @@ int d2d_reset_positions(d2d_handle* h, uint64_t seed, uint64_t episode, const ui
                               rows_here ? h->lpos : nullptr, h->N, h->stream));
     h->have_pos = true;
     h->lpos_dirty = !rows_here;
+    h->have_lo = false;            // the sampler draws float32 coordinates
     return D2D_OK;
 } D2D_CATCH
 

@@ -30,6 +30,7 @@ enum PlMode : int {
 // Byte offsets of one env's LDS arrays (step_lds_layout): only what the configuration reads back is allocated.
 struct StepLds {
     unsigned aux, rx, sinr, sh, expo, tflat, mask, lists, pool, env_bytes;
+    unsigned lo;             // exact positions (StepArgs::lpos_lo): float2 per link (+ stand-in), the low parts of (tx_x, tx_y)
 };
 
 struct StepArgs {
@@ -76,6 +77,10 @@ struct StepArgs {
     const int* act_cols;     // [N] action column of every link (col_mode 1 only; 0 for fixed links)
     const unsigned* side_words;  // [ceil(N / 32)] bit i set <=> link i is a sidelink (host-built with the records)
     const float4* lpos;      // [B, N] (tx_x, tx_y, rx_x, rx_y) of every link, rebuilt when positions / links change
+    const float4* lpos_lo;   // [B, N] or null: the LOW parts of the same four coordinates when the host uploaded float64 positions
+                             // (d2d_set_positions_f64: coordinate = hi + lo, hi = float(v), lo = float(v - hi)).  Kernels compiled with
+                             // OPT_XPOS form every difference as (tx_hi - rx_hi) + (tx_lo - rx_lo): exact to ~1e-7 of the DIFFERENCE
+                             // where float32 absolute coordinates carry 3e-5 m at 500 m (position.py:11-12 works in Python floats)
     const float* gain_table; // PL_TABLE: linear gain, tx major: [D,D] by (tx device, rx device), or [N,N] by (tx link, rx link)
     long long table_env_stride; // 0 or pitch * pitch
     int table_by_link;       // rows / columns are link indices (d2d_set_path_loss_link_table), else device indices
@@ -118,13 +123,14 @@ struct ObsArgs {
 
 hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStream_t stream);
 hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_threads, hipStream_t stream);
-void rollout_lds_layout(int N, int R, int mode, int reward_fn, StepLds* out);
+void rollout_lds_layout(int N, int R, int mode, int reward_fn, int xpos, StepLds* out);
 hipError_t launch_obs_expand(const ObsArgs& a, hipStream_t stream);
-size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists);
-void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out);
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, int xpos);
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, int xpos, StepLds* out);
 hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStream_t stream);
-hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const int4* rec_a, int B, int N, int D,
-                                 float4* lpos, hipStream_t stream);
+hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const float* lo_x, const float* lo_y, const int4* rec_a,
+                                 int B, int N, int D, float4* lpos, float4* lpos_lo, hipStream_t stream);
+hipError_t launch_gain_from_db(const void* pl_db, int is_f64, size_t elems, float* gain, int num_cus, hipStream_t stream);
 hipError_t launch_reset(int B, int D, int C, float cell_radius, float d2d_radius, unsigned long long seed,
                         unsigned long long episode, unsigned long long env_offset, const unsigned char* fixed_mask,
                         const float* fixed_xy, float* pos_x, float* pos_y, float4* lpos, int N, hipStream_t stream);

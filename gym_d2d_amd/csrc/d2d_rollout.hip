@@ -61,12 +61,13 @@ namespace d2d {
 #define RO_ST(ptr, val) do { if (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 
 // LDS of one env (byte offsets; StepLds): 0 sum (u64) ... 60 dump (u16) | 64 flags[4]: env flags, reward bits, ticket, pool count
-// | 80 link[N + 1] tuples | expo[N + 1] (power law) | slots[R + 1] (8 x u16) | cnt[R + 1] | pool[N] (rb, link) | 16 wave sums
+// | 80 link[N + 1] tuples | expo[N + 1] (power law) | lo[N + 1] (exact positions) | slots[R + 1] (8 x u16) | cnt[R + 1] | pool[N] (rb, link) | 16 wave sums
 // (padded link counts) | low[N + 1] (CueSinrShannon).  With two links per thread the region from 80 on becomes the env's table image.
-void rollout_lds_layout(int N, int R, int mode, int reward_fn, StepLds* out) {
+void rollout_lds_layout(int N, int R, int mode, int reward_fn, int xpos, StepLds* out) {
     std::memset(out, 0, sizeof(*out));
     unsigned off = LDS_HEAD_BYTES + ((unsigned)N + 1u) * 16u;
     out->expo = off; if (mode == PL_POWER) off += ((unsigned)N + 1u) * 8u;
+    out->lo = off; if (xpos) off += ((unsigned)N + 1u) * 8u;      // exact positions: low parts of (tx_x, tx_y), + one for the stand-in
     off = (off + 15u) & ~15u;
     out->lists = off; off += ((unsigned)R + 1u) * 16u + (((unsigned)R + 1u + 3u) & ~3u) * 4u;
     out->pool = off; off += (unsigned)N * 8u;
@@ -90,7 +91,11 @@ __device__ __forceinline__ void lds_atomic_or(unsigned addr, int bits) {
 template <int MODE, int OPT, int LPT>
 __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     constexpr bool SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0, PAD = (OPT & OPT_PAD) != 0;
+    // XPOS: float64 positions uploaded as (hi, lo) float pairs (d2d_set_positions_f64): one more 16-byte row per link, one more
+    // ds_read_b64 per pair, every difference by coord_diff.  One link per thread (the two-link kernel sits at its 64-VGPR limit).
+    constexpr bool XPOS = (OPT & OPT_XPOS) != 0;
     static_assert(!PAD || (LPT == 1 && !SREC), "a link count that is no multiple of 64: one link per thread, per-lane records");
+    static_assert(!XPOS || LPT == 1, "exact positions: one link per thread");
     constexpr bool POWLAW = MODE == PL_POWER;
     static_assert(MODE == PL_INV_SQUARE || MODE == PL_POWER, "the rollout kernel serves the power laws");
     static_assert(LPT == 1 || LPT == 2, "one or two links per thread");
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     const bool shannon_reward = a.reward_fn == 2;                // link, looks at the other members of the RB: one link per thread only)
     const bool cue_sinr_reward = LPT == 1 && a.reward_fn == 3;
     const unsigned EMPTY = (unsigned)N * 16u;                    // byte offset of the stand-in tuple link[N]
-    const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
+    const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_LO = a.lds.lo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
     const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u, L_RED = a.lds.aux, L_LOW = a.lds.rx;
 
     RO_STAMP(0);
@@ -126,10 +131,12 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             if (LPT == 1) in[u].act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
             in[u].act1 = 0;
             in[u].pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
+            in[u].plo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (XPOS) in[u].plo = *at(a.lpos_lo, fresh((row + (unsigned)i) * 16u));
         } else {
             // (per-lane records: a PREFIX of the links may carry fixed actions - traffic-model CUEs, traffic_model.py:15-32 - and the
             // action array then has a column per remaining link only)
-            in[u] = load_link(a, row, act_row, i, 0, 0, false, false, POWLAW);
+            in[u] = load_link(a, row, act_row, i, 0, 0, false, false, POWLAW, XPOS);
         }
     }
 
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         if (tid == TPE - 1) {
             lds_put<f32x4>(L_LINK + EMPTY, f32x4{1.0e18f, 1.0e18f, -0.0f, __int_as_float(-1)});
             if (POWLAW) lds_put<f32x2>(L_EXPO + (EMPTY >> 1), f32x2{-1.0f, 0.0f});
+            if (XPOS) lds_put<f32x2>(L_LO + (EMPTY >> 1), f32x2{0.0f, 0.0f});
         }
         if (tid < 5) lds_put<u32x4>((unsigned)tid * 16u, u32x4{0u, 0u, 0u, 0u});          // sum, dump, flags[4]: 80 bytes
         if (PAD && tid >= 8 && tid < 12) lds_put<u32x4>(L_RED + (unsigned)(tid - 8) * 16u, u32x4{0u, 0u, 0u, 0u});
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         lds_put<f32x2>(L_LINK + my_off, f32x2{in[u].pos.x, in[u].pos.y});
         lds_put<f32x2>(L_LINK + my_off + 8u, f32x2{pz[u], __int_as_float(rb[u])});
         if (POWLAW) lds_put<f32x2>(L_EXPO + (my_off >> 1), f32x2{in[u].hh.x, in[u].hh.y});
+        if (XPOS) lds_put<f32x2>(L_LO + (my_off >> 1), f32x2{in[u].plo.x, in[u].plo.y});
         pwr[u] = pw;
         row_off[u] = L_SLOTS + rbc * 16u;
         slot[u] = shadow ? 0u : lds_atomic_inc(L_CNT + rbc * 4u);
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         const unsigned my_off = (unsigned)i << 4;
         const int type = (in[u].ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
         const float2 rx = make_float2(in[u].pos.z, in[u].pos.w);
+        const float2 rxlo = make_float2(in[u].plo.z, in[u].plo.w);   // zero unless XPOS
         const float rx_pl = in[u].rb_.y, rx_lin = in[u].rb_.z, noise = in[u].rb_.w;
         const float sens = in[u].rc.x, bw_mhz = in[u].rc.y;
         int dmin = 0x7F000000;                                   // power law: bits of the smallest squared distance met
@@ -263,7 +273,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // one (transmitter tuple at LDS offset e) -> (this receiver) term: simulator.py:97-101, linear mW
         const auto term = [&](unsigned e, int& dmin_) {
             const f32x4 o = lds_get<f32x4>(L_LINK + e);
-            const float dx = o.x - rx.x, dy = o.y - rx.y;
+            float dx = o.x - rx.x, dy = o.y - rx.y;
+            if (XPOS) { const float2 l = lds_f2(L_LO + (e >> 1)); dx = coord_diff(o.x, rx.x, l.x, rxlo.x); dy = coord_diff(o.y, rx.y, l.y, rxlo.y); }
             const float d2 = fmaf(dx, dx, dy * dy);
             const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (e >> 1)) : make_float2(-1.0f, 0.0f));
             if (POWLAW) dmin_ = min(dmin_, __float_as_int(d2));
@@ -277,7 +288,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             for (int j = 0; j < N; ++j) {
                 const f32x4 o = lds_get<f32x4>(L_LINK + ((unsigned)j << 4));
                 const bool same = (__float_as_int(o.w) == rb[u]) & (j != i);
-                const float dx = o.x - rx.x, dy = o.y - rx.y;
+                float dx = o.x - rx.x, dy = o.y - rx.y;
+                if (XPOS) { const float2 l = lds_f2(L_LO + ((unsigned)j << 3)); dx = coord_diff(o.x, rx.x, l.x, rxlo.x); dy = coord_diff(o.y, rx.y, l.y, rxlo.y); }
                 const float d2 = fmaf(dx, dx, dy * dy);
                 const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + ((unsigned)j << 3)) : make_float2(-1.0f, 0.0f));
                 if (POWLAW) dmin_ = same ? min(dmin_, __float_as_int(d2)) : dmin_;
@@ -289,7 +301,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // own link: simulator.py:93 (first: its term opens the interference sum below)
         float d2_own, g_own;
         {
-            const float dx = in[u].pos.x - rx.x, dy = in[u].pos.y - rx.y;
+            const float dx = XPOS ? coord_diff(in[u].pos.x, rx.x, in[u].plo.x, rxlo.x) : in[u].pos.x - rx.x;
+            const float dy = XPOS ? coord_diff(in[u].pos.y, rx.y, in[u].plo.y, rxlo.y) : in[u].pos.y - rx.y;
             d2_own = fmaf(dx, dx, dy * dy);
             g_own = pair_gain<MODE>(d2_own, in[u].hh);
         }
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
                                         mlist.z & 0xFFFFu, mlist.z >> 16, mlist.w & 0xFFFFu, mlist.w >> 16};
         // .difference({action}) (simulator.py:95) by arithmetic: the own entry is among the slots, so the sum opens at minus
         // its term (pz * g_own - the very product the slot's evaluation repeats, same operands, same rounding)
-        const f32x2 rxv = {rx.x, rx.y};
+        const f32x2 rxv = {rx.x, rx.y}, rxlov = {rxlo.x, rxlo.y};
         double acc = -(double)(pz[u] * g_own);
         // The empty slots' stand-in has power -0.0: its term, -0.0, leaves the sum alone and its bits, 0x80000000, are neutral
         // for BOTH extremes - below every real term as a signed integer (the maximum), above every one as an unsigned (the
@@ -314,7 +327,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         unsigned tmin = 0xFFFFFFFFu;
 #define RO_PAIR(k, o)                                                                                                   \
         {                                                                                                               \
-            const f32x2 dd = f32x2{(o).x, (o).y} - rxv;               /* one v_pk_add_f32: (x, y) sit in adjacent registers */ \
+            f32x2 dd = f32x2{(o).x, (o).y} - rxv;                     /* one v_pk_add_f32: (x, y) sit in adjacent registers */ \
+            if (XPOS) dd = dd + (lds_get<f32x2>(L_LO + (off[k] >> 1)) - rxlov);   /* coord_diff, both coordinates at once */ \
             const float d2 = fmaf(dd.x, dd.x, dd.y * dd.y);                                                             \
             const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (off[k] >> 1)) : make_float2(-1.0f, 0.0f));    \
             if (POWLAW) dmin = min(dmin, __float_as_int(d2));                                                           \
@@ -353,7 +367,10 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
 #undef RO_PAIR
         // all partial sums exact <=> the sum is the ascending-order sum: largest and smallest non-zero term within 2^25
         // (nine values of 24 bits inside the 53 of a double); compared on the raw bits (conservative by less than one binade)
-        const bool inexact = (unsigned)tmax - tmin >= (25u << 23);
+        // ... and a non-finite OWN term (transmitter and receiver in one place under 1 / d^2: inf) cannot be taken back out of the sum
+        // (-inf + inf = NaN where the generic kernels, which leave the own link out, keep the interferers' finite sum): any inf / NaN
+        // among the terms sends the lane to the sorted sum, which excludes the own entry
+        const bool inexact = ((unsigned)tmax - tmin >= (25u << 23)) | (tmax >= 0x7F800000);
         const bool big = members > (unsigned)RO_SLOTS;           // more members than the row holds: the rest is in the pool
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(inexact | big | oor[u]) != 0ull)) {
             if (oor[u]) {
@@ -663,12 +680,23 @@ hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_thr
         case OPT_NT: D2D_RO_1(M, OPT_NT, L); break;                                                      \
         default: D2D_RO_1(M, OPT_SREC | OPT_NT, L); break;                                               \
     }
+#define D2D_RO_X(M)                                     /* exact positions: one link per thread */         \
+    switch (opt & (OPT_SREC | OPT_NT | OPT_PAD)) {                                                       \
+        case 0: D2D_RO_1(M, OPT_XPOS, 1); break;                                                         \
+        case OPT_SREC: D2D_RO_1(M, OPT_XPOS | OPT_SREC, 1); break;                                       \
+        case OPT_NT: D2D_RO_1(M, OPT_XPOS | OPT_NT, 1); break;                                           \
+        case OPT_SREC | OPT_NT: D2D_RO_1(M, OPT_XPOS | OPT_SREC | OPT_NT, 1); break;                     \
+        case OPT_PAD: D2D_RO_1(M, OPT_XPOS | OPT_PAD, 1); break;                                         \
+        default: D2D_RO_1(M, OPT_XPOS | OPT_PAD | OPT_NT, 1); break;                                     \
+    }
 #define D2D_RO(M) do {                                                                                   \
-        if (opt & OPT_PAD) { if (opt & OPT_NT) D2D_RO_1(M, OPT_PAD | OPT_NT, 1); else D2D_RO_1(M, OPT_PAD, 1); }  \
+        if (opt & OPT_XPOS) { D2D_RO_X(M) }                                                              \
+        else if (opt & OPT_PAD) { if (opt & OPT_NT) D2D_RO_1(M, OPT_PAD | OPT_NT, 1); else D2D_RO_1(M, OPT_PAD, 1); }  \
         else if (a.lpt == 2) { D2D_RO_L(M, 2) } else { D2D_RO_L(M, 1) }                                  \
     } while (0)
     if (mode == PL_INV_SQUARE) D2D_RO(PL_INV_SQUARE); else D2D_RO(PL_POWER);
 #undef D2D_RO
+#undef D2D_RO_X
 #undef D2D_RO_L
 #undef D2D_RO_1
     return err;

@@ -49,7 +49,7 @@
 
 namespace d2d {
 
-void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, StepLds* out) {
+void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, int xpos, StepLds* out) {
     // lists: one more tuple (and exponent) behind the last link - the far-away, zero-power stand-in an empty list slot reads
     const unsigned NL = (unsigned)N + (lists ? 1u : 0u);
     unsigned off = LDS_HEAD_BYTES + NL * 16u;
@@ -59,6 +59,7 @@ void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int re
     off = (off + 7u) & ~7u;
     out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW) off += NL * 8u;      // (head, tail) of -exponent / 2 per link
     off = (off + 7u) & ~7u;
+    out->lo = off; if (xpos) off += NL * 8u;                                         // low parts of (tx_x, tx_y) per link (exact positions)
     out->tflat = off; if (fuse_obs) off += (unsigned)N * 24u;
     off = (off + 15u) & ~15u;                            // the mask region is cleared with 16-byte stores
     out->mask = off;
@@ -71,9 +72,9 @@ void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int re
     out->env_bytes = (off + 15u) & ~15u;
 }
 
-size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists) {
+size_t step_lds_bytes_per_env(int N, int R, int mask_words, int fuse_obs, int lpt, int reward_fn, int mode, int lists, int xpos) {
     StepLds l;
-    step_lds_layout(N, R, mask_words, fuse_obs, lpt, reward_fn, mode, lists, &l);
+    step_lds_layout(N, R, mask_words, fuse_obs, lpt, reward_fn, mode, lists, xpos, &l);
     return l.env_bytes;
 }
 
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr int KEEP = LPT > 0 ? LPT : 1;
     constexpr int UNROLL_LINKS = LPT > 0 ? LPT : 1;                // strided kernels: the per-link bodies are not unrolled
     constexpr bool LISTS = (OPT & OPT_LISTS) != 0, SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0;
+    constexpr bool XPOS = (OPT & OPT_XPOS) != 0;                   // float64 positions as (hi, lo) pairs: coord_diff (d2d_step_device.h)
+    static_assert(!XPOS || HOT == 0, "the specialised kernels serve float32 positions (device-side resets)");
     constexpr bool POWLAW = MODE == PL_POWER || MODE == PL_SHADOW;   // per-link exponents (rec_h, LDS expo[])
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
     const int cfg_col_mode = HOT ? 0 : a.col_mode;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) {
         const int i = lt + u * TPE;
-        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1, SREC, POWLAW);
+        first[u] = load_link(a, b_ld * (unsigned)N, b_ld * (unsigned)a.act_stride, FULL || i < N ? i : N - 1, cfg_action_mode, cfg_col_mode, HOT == 1, SREC, POWLAW, XPOS);
     }
     // ---- pass 0: clear masks and flags
     const bool have_masks = HOT || W > 0;                          // mask region allocated
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             if (lt == TPE - 1) {
                 s.link[N] = make_float4(1.0e18f, 1.0e18f, 0.0f, __int_as_float(-1));
                 if (POWLAW) s.expo[N] = make_float2(-1.0f, 0.0f);
+                if (XPOS) s.lo[N] = make_float2(0.0f, 0.0f);
             }
         } else if (want_masks) clear_masks<FULL>(s, R, W, lt, TPE);
         if (lt < 5) reinterpret_cast<uint4*>(s.red)[lt] = make_uint4(0u, 0u, 0u, 0u);   // red[16] + flags[4]: 80 bytes
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 #pragma unroll
     for (int u = 0; u < KEEP; ++u) { me0[u] = make_float4(0.f, 0.f, 0.f, 0.f); myslot[u] = 0u; }
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1, false, POWLAW);
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1, false, POWLAW, XPOS);
         int rb, p;
         decode_link(a, in, act_row, rb, p, cfg_action_mode, HOT == 1);
         const int type = (in.ra.x >> D2D_REC_TYPE_SHIFT) & D2D_REC_TYPE_MASK;
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (!HOT) s.aux[i] = MODE == PL_TABLE && a.table_by_link ? (i | (in.ra.x & 0x0F000000)) : (in.ra.x & 0x0FFFFFFF);
         if (IN_REGS(u)) me0[KEPT(u)] = tuple;                            // own links stay in registers for pass 2
         if (POWLAW) s.expo[i] = in.hh;
+        if (XPOS) s.lo[i] = make_float2(in.plo.x, in.plo.y);
         if (cfg_export_actions && !ABL(32)) { const unsigned oe = fresh((row + (unsigned)i) * 4u); ST(at(a.rb_out, oe), rb); ST(at(a.pwr_out, oe), p); }
         if (LISTS) {
             if (LIKELY((unsigned)rb < (unsigned)R)) {
@@ -287,9 +292,15 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     int my_flags = 0;
     bool violated = false;
     FOR_MY_LINKS(u, i) {
-        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1, false, POWLAW);   // strided links: records re-read (L2)
+        const LinkRaw in = IN_REGS(u) ? first[KEPT(u)] : load_link(a, row, act_row, i, cfg_action_mode, cfg_col_mode, HOT == 1, false, POWLAW, XPOS);   // strided links: records re-read (L2)
         const float4 me = IN_REGS(u) ? me0[KEPT(u)] : s.link[i];
         const float2 rx = make_float2(in.pos.z, in.pos.w);
+        const float2 rxlo = make_float2(in.plo.z, in.plo.w);               // zero unless XPOS
+        // tx (tuple o of link j) - rx, per coordinate: position.py:11-12
+#define D2D_DXY(o, j)                                                                                                   \
+        float dx, dy;                                                                                                   \
+        if (XPOS) { const float2 l_ = s.lo[j]; dx = coord_diff((o).x, rx.x, l_.x, rxlo.x); dy = coord_diff((o).y, rx.y, l_.y, rxlo.y); } \
+        else { dx = (o).x - rx.x; dy = (o).y - rx.y; }
         const int rb = __float_as_int(me.w);
         // a link whose own rb lies outside [0, R) has no mask row: it (and only it) takes the all-pairs sweep - links
         // with an in-range rb never share it with such a link, so their mask walk is complete
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             sort8(v);
 #define D2D_LIST_PAIR(o, j)                                                                                             \
             {                                                                                                           \
-                const float dx = (o).x - rx.x, dy = (o).y - rx.y;                                                       \
+                D2D_DXY(o, j)                                                                                           \
                 const float d2 = fmaf(dx, dx, dy * dy);                                                                 \
                 float g;                                                                                                \
                 if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];                                \
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         const int j = jbase + __builtin_ctz(bits);
                         bits &= bits - 1u;
                         const float4 o = s.link[j];
-                        const float dx = o.x - rx.x, dy = o.y - rx.y;
+                        D2D_DXY(o, j)
                         const float d2 = fmaf(dx, dx, dy * dy);
                         float g;
                         if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                             const int j = (w << 5) + __builtin_ctz(bits);
                             bits &= bits - 1u;
                             const float4 o = s.link[j];
-                            const float dx = o.x - rx.x, dy = o.y - rx.y;
+                            D2D_DXY(o, j)
                             const float d2 = fmaf(dx, dx, dy * dy);
                             float g;
                             if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             for (int j = 0; j < N; ++j) {
                 const float4 o = s.link[j];                              // same address in every lane: LDS broadcast
                 const bool same = (__float_as_int(o.w) == rb) & (j != i);
-                const float dx = o.x - rx.x, dy = o.y - rx.y;
+                D2D_DXY(o, j)
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol] : 0.0f;
@@ -479,8 +490,10 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
             const unsigned o4x = fresh((row + (unsigned)i) * 4u);
             *at(a.rate, o4x) = 0.0f; *at(a.cap, o4x) = 0.0f; *at(a.snr_db, o4x) = 0.0f; *at(a.sinr_db, o4x) = 0.0f;
         }
+#undef D2D_DXY
         // own link: simulator.py:93
-        const float dx = me.x - rx.x, dy = me.y - rx.y;
+        const float dx = XPOS ? coord_diff(me.x, rx.x, in.plo.x, rxlo.x) : me.x - rx.x;
+        const float dy = XPOS ? coord_diff(me.y, rx.y, in.plo.y, rxlo.y) : me.y - rx.y;
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)(a.table_by_link ? i : txd) * a.table_pitch + tcol];
@@ -806,8 +819,9 @@ hipError_t launch_flags_or(const int* env_flags, int B, unsigned* status, hipStr
 // (simulator.py:61-75 only moves devices in reset()), so that the step kernel's prologue is a single coalesced 16-byte
 // load per link instead of a dependent link table -> device position double hop.
 __global__ __launch_bounds__(256) void link_positions_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                            const float* __restrict__ lx, const float* __restrict__ ly,
                                                             const int4* __restrict__ rec_a, int B, int N, int D,
-                                                            float4* __restrict__ lpos) {
+                                                            float4* __restrict__ lpos, float4* __restrict__ lpos_lo) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)B * N) return;
     const int b = (int)(gid / N), i = (int)(gid - (size_t)b * N);
@@ -815,14 +829,15 @@ __global__ __launch_bounds__(256) void link_positions_kernel(const float* __rest
     const size_t base = (size_t)b * D;
     const int txd = ra.x & D2D_REC_TXDEV_MASK, rxd = ra.y;
     lpos[gid] = make_float4(px[base + txd], py[base + txd], px[base + rxd], py[base + rxd]);
+    if (lpos_lo) lpos_lo[gid] = make_float4(lx[base + txd], ly[base + txd], lx[base + rxd], ly[base + rxd]);   // exact positions: the low parts
 }
 
-hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const int4* rec_a, int B, int N, int D,
-                                 float4* lpos, hipStream_t stream) {
+hipError_t launch_link_positions(const float* pos_x, const float* pos_y, const float* lo_x, const float* lo_y, const int4* rec_a,
+                                 int B, int N, int D, float4* lpos, float4* lpos_lo, hipStream_t stream) {
     const size_t total = (size_t)B * N;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(link_positions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pos_x, pos_y,
-                       rec_a, B, N, D, lpos);
+                       lo_x, lo_y, rec_a, B, N, D, lpos, lpos_lo);
     return hipGetLastError();
 }
 
@@ -835,15 +850,16 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool lists = a.walk == 2 && lpt > 0 && a.reward_fn != 3;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 &&
                      (a.walk == 0 || lists) && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
-                     a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER);
+                     a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER) && !a.lpos_lo;
     const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0);
-    if (a.rollout) return launch_rollout(a, mode, a.N % 64 ? (hot_opt & OPT_NT) | OPT_PAD : hot_opt, block_threads, stream);
+    const int xp = a.lpos_lo ? OPT_XPOS : 0;                   // float64 positions (d2d_set_positions_f64): the coord_diff kernels
+    if (a.rollout) return launch_rollout(a, mode, (a.N % 64 ? (hot_opt & OPT_NT) | OPT_PAD : hot_opt) | xp, block_threads, stream);
     // the rollout configuration with member lists has a kernel of its own (d2d_rollout.hip; chosen by run_step)
     // level 2: several small envs per workgroup with the LinearObs expansion fused (BASELINE config 2), a fixed prefix
     // (traffic-model CUEs) allowed
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
                       a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 && a.mask_words > 0 &&
-                      a.fuse_obs == 4 && a.obs_q_per_row > 0 &&
+                      a.fuse_obs == 4 && a.obs_q_per_row > 0 && !a.lpos_lo &&
                       (mode == PL_INV_SQUARE || mode == PL_POWER);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
@@ -870,11 +886,12 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
         else if (lpt == 2) D2D_LAUNCH_1(M, 2, false, 0, L);                                              \
         else if (lpt == 1 && full) D2D_LAUNCH_1(M, 1, true, 0, L);                                       \
         else if (lpt == 1) D2D_LAUNCH_1(M, 1, false, 0, L);                                              \
-        else D2D_LAUNCH_1(M, 0, false, 0, 0);                                                            \
+        else D2D_LAUNCH_1(M, 0, false, 0, (L) & OPT_XPOS);                                               \
     } while (0)
 #define D2D_LAUNCH_COLD(M)                                                                               \
     do {                                                                                                 \
-        if (lists) D2D_LAUNCH_L(M, OPT_LISTS);                                                           \
+        if (xp) { if (lists) D2D_LAUNCH_L(M, OPT_LISTS | OPT_XPOS); else D2D_LAUNCH_L(M, OPT_XPOS); }    \
+        else if (lists) D2D_LAUNCH_L(M, OPT_LISTS);                                                      \
         else D2D_LAUNCH_L(M, 0);                                                                         \
     } while (0)
 #define D2D_LAUNCH(M)                                                                                    \

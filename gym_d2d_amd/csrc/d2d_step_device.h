@@ -114,16 +114,40 @@ __device__ __forceinline__ void philox_step(unsigned c0, unsigned c1, unsigned c
     o0 = c0; o1 = c1;
 }
 
+// cos(2 pi u) for u = k * 2^-24 in [0, 1): the quadrant reduction is EXACT in these units (4u splits into an integer quadrant and a
+// fraction with no rounding), then one rounding of x = f * pi / 2 and a minimax polynomial on [-pi/4, pi/4] (the reset sampler's
+// sincos_turns, csrc/d2d_reset.hip).  cosf(fl(2 pi u)) carries the argument's rounding - 3.7e-7 near 2 pi, times a Gaussian of up
+// to 5.9, times chi dB: most of the 1e-5 bar where |sinr_db| < 1.
+__device__ __forceinline__ float cos_turns(float u) {
+    const float t = 4.0f * u;                                           // [0, 4), exact
+    float q = floorf(t);
+    float f = t - q;                                                    // [0, 1), exact
+    if (f > 0.5f) { f -= 1.0f; q += 1.0f; }                             // [-0.5, 0.5], exact
+    const float x = f * 1.5707963267948966f, z = x * x;
+    const float s = fmaf(x * z, fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), x);
+    const float c = fmaf(z * z, fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), fmaf(-0.5f, z, 1.0f));
+    const int k = (int)q;
+    const float b = (k & 1) ? s : c;                                    // quarter turns: cos -> -sin -> -cos -> sin
+    return ((k + 1) & 2) ? -b : b;
+}
+
 // Linear-domain factor 10^(-X/10), X ~ N(0, chi^2) dB, for the call (tx link j -> rx link i, kind) of this step.
 // ShadowingPathLoss.__call__ draws gauss(0, chi) on EVERY call with d > d0 (path_loss.py:76-79): the signal term of
 // the SINR (kind 0, j == i), every interferer term (kind 0, j != i) and the SNR's own re-evaluation of the signal
 // path loss (kind 1, simulator.py:114) are independent draws.
+// Box-Muller to ~1e-7 absolute in z (round 6; the oracle does the same transform of the same words in double): u1 = (k + 0.5) 2^-24 is
+// a float32 value only for k < 2^23 - above, k + 0.5 needs 25 bits and rounds, and near u1 = 1 the Gaussian's radius sqrt(-2 ln u1)
+// amplifies that by 1 / (z u1) (z = 0.01: 3e-6; the largest k: the radius itself) - so the upper half goes through
+// log1p(-(1 - u1)), whose argument (2^24 - k - 0.5) 2^-24 IS exact; the angle by cos_turns.
 __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, int j, int i, unsigned kind) {
     unsigned w0, w1;
     philox_step(env, a.shadow_step, (unsigned)j | ((unsigned)i << 16), kind, a.shadow_seed_lo, a.shadow_seed_hi, w0, w1);
-    const float u1 = ((float)(w0 >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1)
+    const unsigned k1 = w0 >> 8;
+    const float lo_half = logf(((float)(k1 & 0x7FFFFFu) + 0.5f) * 5.9604644775390625e-08f);                 // k1 < 2^23: exact argument
+    const float hi_half = log1pf(-(((float)(0x1000000u - k1) - 0.5f) * 5.9604644775390625e-08f));          // k1 >= 2^23: 1 - u1 exact
+    const float nl = -(k1 < 0x800000u ? lo_half : hi_half);                                                 // -ln(u1), u1 in (0, 1)
     const float u2 = (float)(w1 >> 8) * 5.9604644775390625e-08f;               // [0, 1)
-    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+    const float z = sqrtf(2.0f * nl) * cos_turns(u2);                          // Box-Muller
     return exp2f(-0.33219280948873623f * a.shadow_chi * z);                     // 10^(-chi z / 10)
 }
 
@@ -135,6 +159,7 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
 //        rx[N] float2                                           strided links only (LPT == 0)
 //        sinr[N], sh[N] f32                                     Shannon / CueSinrShannon rewards
 //        expo[N] float2 (head, tail of -exponent / 2)          power-law / shadowing path loss
+//        lo[N] float2 (low parts of tx_x, tx_y)                 exact positions (OPT_XPOS)
 //        tflat[6N] f32                                          fused obs expansion
 //   off_mask: mask[W][R] u32 per-RB membership, word-major (lanes with different RBs hit different banks),
 //             side[W] u32 sidelink membership, summ[R] u32 (bit w set <=> mask[w][rb] != 0)
@@ -142,7 +167,7 @@ __device__ __forceinline__ float shadow_factor(const StepArgs& a, unsigned env, 
 #define LDS_HEAD_BYTES 80u
 
 struct Smem {
-    float* red; int* flags; float4* link; float2* rx; float* sinr; float* sh; float2* expo; int* aux; float* tflat;
+    float* red; int* flags; float4* link; float2* rx; float* sinr; float* sh; float2* expo; float2* lo; int* aux; float* tflat;
     unsigned* mask; unsigned* side; unsigned* summ;
     uint4* slots; unsigned* cnt;
 };
@@ -157,6 +182,7 @@ __device__ __forceinline__ Smem carve(unsigned char* base, const StepLds& l, uns
     s.sinr = reinterpret_cast<float*>(base + l.sinr);
     s.sh = reinterpret_cast<float*>(base + l.sh);
     s.expo = reinterpret_cast<float2*>(base + l.expo);
+    s.lo = reinterpret_cast<float2*>(base + l.lo);
     s.tflat = reinterpret_cast<float*>(base + l.tflat);
     s.mask = reinterpret_cast<unsigned*>(base + l.mask);
     s.side = s.mask + R * W;
@@ -190,6 +216,7 @@ struct LinkRaw {
     float4 rc;           // rec_c: sens_db, bw_mhz, exponent, (P | column << 16)
     float2 hh;           // rec_h: head / tail of -exponent / 2 (power-law and shadowing modes only)
     float4 pos;          // tx_x, tx_y, rx_x, rx_y
+    float4 plo;          // OPT_XPOS: the low parts of the same four coordinates (StepArgs::lpos_lo), else zero
     int act0, act1;      // raw action, or explicit (rb, pwr)
 };
 
@@ -212,9 +239,10 @@ __device__ __forceinline__ i32x2 scalar_load8(const void* p) {
 }
 
 __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, unsigned act_row, int i, int action_mode, int col_mode,
-                                             bool no_fixed = false, bool srec = false, bool need_h = false) {
+                                             bool no_fixed = false, bool srec = false, bool need_h = false, bool xpos = false) {
     LinkRaw in;
     in.act0 = 0; in.act1 = 0;
+    in.plo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     in.hh = make_float2(-1.0f, 0.0f);
     // actions first, branch-free per lane (uniform branches only), so that no join forces a wait on the loads in flight
     if (action_mode == 0) {
@@ -250,8 +278,16 @@ __device__ __forceinline__ LinkRaw load_link(const StepArgs& a, unsigned row, un
         if (need_h) in.hh = a.rec_h[i];
     }
     in.pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
+    if (xpos) in.plo = *at(a.lpos_lo, fresh((row + (unsigned)i) * 16u));
     return in;
 }
+
+// One coordinate difference tx - rx.  Plain float32 positions: one subtraction.  OPT_XPOS (float64 positions uploaded as hi + lo
+// pairs, d2d_set_positions_f64): (tx_hi - rx_hi) + (tx_lo - rx_lo) - the first difference is exact whenever the two are within a
+// factor of two of each other (Sterbenz), i.e. exactly where absolute float32 coordinates lose the difference (a receiver 0.1 m from
+// a transmitter 500 m out: 3e-5 m of rounding on each), and the low parts restore what the rounding to float32 took.  Every kernel
+// forms it in this order, so they agree bit for bit.  (position.py:11-12: the reference subtracts Python floats.)
+__device__ __forceinline__ float coord_diff(float tx_hi, float rx_hi, float tx_lo, float rx_lo) { return (tx_hi - rx_hi) + (tx_lo - rx_lo); }
 
 // (rb, tx power dBm) of a link: fixed by the traffic model (traffic_model.py:15-32), decoded from the raw action
 // (d2d_env.py:94-96, Python floor semantics; NB due_min_tx_power_dBm is not added back), or given explicitly.
@@ -353,5 +389,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define OPT_SREC 2       /* rollout kernel: link records by scalar loads (StepArgs::rec_uniform) */
 #define OPT_NT 4         /* rollout kernel: nontemporal result stores (StepArgs::nt_results) */
 #define OPT_PAD 8        /* rollout kernel: N is no multiple of 64 (threads beyond the last link shadow it) */
+#define OPT_XPOS 16      /* exact positions: every coordinate is a (hi, lo) float pair (StepArgs::lpos_lo, d2d_set_positions_f64) */
 
 }  // namespace d2d

@@ -149,7 +149,11 @@ class VecD2DEnv:
         mode = self.obs_fn.native_mode
         fused = mode == _native.OBS_LINEAR and self.num_links <= 128 and not getattr(self, '_native_obs64', False)
         self._placement_target = ('obs', _native.BUF_OBS) if fused else (('table', _native.BUF_OBS_TABLE) if mode == _native.OBS_TABLE else None)
-        self._placement_trials = int(placement_trials) if self.use_torch and self._placement_target is not None else 0
+        if placement_trials in ('auto', None):             # the default of rounds 3 - 4; since round 5 the trials are opt-in
+            placement_trials = 0
+        if not isinstance(placement_trials, int) or isinstance(placement_trials, bool) or placement_trials < 0:
+            raise ValueError("placement_trials must be a non-negative int (0 = off; 'auto' is accepted as 0)")
+        self._placement_trials = placement_trials if self.use_torch and self._placement_target is not None else 0
         self._placement_budget = int(placement_budget_bytes)
         self.placement = None                      # after the trials: {'buffer': ..., 'us_per_step': [...], 'chosen': k}
 
@@ -293,7 +297,8 @@ class VecD2DEnv:
             pool = torch.cuda.MemPool() if hasattr(torch.cuda, 'MemPool') else None
             if pool is None:
                 return None, (torch.empty_like(like) if like is not None else torch.empty(nbytes_, dtype=torch.uint8, device=self.device))
-            with torch.cuda.use_mem_pool(pool):
+            # use_mem_pool routes the allocations of ONE device: name the env's, which need not be the current one
+            with torch.cuda.device(self.device), torch.cuda.use_mem_pool(pool, device=self.device):
                 t = torch.empty_like(like) if like is not None else torch.empty(nbytes_, dtype=torch.uint8, device=self.device)
             return pool, t
         cands, pools, pads, times = [first], [None], [], []

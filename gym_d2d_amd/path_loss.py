@@ -9,6 +9,9 @@ so `power_law_columns(devices)` returns the three per-device float64 columns for
 and the kernel evaluates gain = 10^(-(a_tx+a_rx)/10) * d^-n in the linear domain (one v_rcp per pair when n == 2).
 A user subclass that only defines __call__ is evaluated on the host once per episode into a [D,D] table
 (`table_db`, d2d_set_path_loss_table) - legal because positions are static between resets (simulator.py:61-75).
+For batches a per-object __call__ is B x N x N Python calls per reset (1.1e9 at 4096 x 512): `ArrayPathLoss` is the
+array-native form of the same plugin - compute(view) -> pl_db[B,N,N] on whole arrays (torch CUDA tensors in a batch, NumPy
+for a single pair), handed to the library from device memory (d2d_set_path_loss_link_table_dev).
 """
 from __future__ import annotations
 
@@ -61,6 +64,75 @@ class PathLoss(ABC):
                 except (ValueError, ZeroDivisionError):
                     pass
         return out
+
+
+class PathLossView:
+    """What ArrayPathLoss.compute sees: the transmitter and receiver coordinates of the links that act, as arrays, plus the
+    Device objects for their static attributes.
+
+        xp                    the array module: torch (batch on the GPU) or numpy (a single pair, or no torch)
+        tx_x, tx_y            [B, N]  transmitter of link j            rx_x, rx_y   [B, N]  receiver of link i
+        tx_devices, rx_devices   length-N lists of Device (antenna gains, heights, ... - the attributes device.py:85-173 exposes)
+        distance()            [B, N, N] float64   d[b, j, i] = |tx of link j - rx of link i| (position.py:11-12)
+        tx_column(fn) / rx_column(fn)   fn(device) per transmitter / receiver as an array shaped [1, N, 1] / [1, 1, N]
+
+    pl_db[b, j, i] = PathLoss(tx of link j, rx of link i): j == i is the link's own signal path (simulator.py:93,114), j != i
+    an interferer's (simulator.py:97-101) - the pairs d2d_set_path_loss_link_table names."""
+
+    def __init__(self, xp, tx_x, tx_y, rx_x, rx_y, tx_devices, rx_devices, like=None):
+        self.xp = xp
+        self.tx_x, self.tx_y, self.rx_x, self.rx_y = tx_x, tx_y, rx_x, rx_y
+        self.tx_devices, self.rx_devices = list(tx_devices), list(rx_devices)
+        self._like = like if like is not None else tx_x
+
+    def _f64(self, a):
+        return a.double() if self.xp.__name__ == 'torch' else np.asarray(a, dtype=np.float64)
+
+    def distance(self):
+        dx = self._f64(self.tx_x)[:, :, None] - self._f64(self.rx_x)[:, None, :]       # float32 coordinates subtract exactly in float64
+        dy = self._f64(self.tx_y)[:, :, None] - self._f64(self.rx_y)[:, None, :]
+        return self.xp.sqrt(dx * dx + dy * dy)
+
+    def _column(self, devices, fn, shape):
+        vals = np.array([float(fn(d)) for d in devices], dtype=np.float64).reshape(shape)
+        if self.xp.__name__ == 'torch':
+            return self.xp.as_tensor(vals, device=self._like.device)
+        return vals
+
+    def tx_column(self, fn):
+        return self._column(self.tx_devices, fn, (1, -1, 1))
+
+    def rx_column(self, fn):
+        return self._column(self.rx_devices, fn, (1, 1, -1))
+
+
+class ArrayPathLoss(PathLoss):
+    """Array-native PathLoss plugin (the batched counterpart of path_loss.py:12-25, as ArrayObsFunction is of ObsFunction):
+    subclasses define compute(view) -> pl_db [B, N, N] with the array module `view.xp`.  The per-object call the reference's
+    contract asks for (`model(tx, rx) -> dB`) is derived from it - one pair through the same compute - so the single-env D2DEnv
+    and a batch run the same formula:
+
+        class TwoSlope(ArrayPathLoss):
+            def compute(self, view):
+                d = view.distance()
+                near = 20 * view.xp.log10(d) + 38.0
+                far = 35 * view.xp.log10(d) - 15 * math.log10(50.0) + 38.0
+                return view.xp.where(d <= 50.0, near, far) - view.tx_column(lambda t: t.tx_antenna_gain_dBi)
+
+    A batch evaluates it once per reset on the GPU (torch) and hands the result to the library from device memory
+    (d2d_set_path_loss_link_table_dev): no host table, no Python loop."""
+
+    @abstractmethod
+    def compute(self, view: PathLossView):
+        """pl_db[b, j, i] in dB for the transmitter of link j and the receiver of link i, shape [B, N, N]."""
+
+    def __call__(self, tx: Device, rx: Device) -> float:
+        one = lambda v: np.array([[float(v)]], dtype=np.float64)
+        view = PathLossView(np, one(tx.position.x), one(tx.position.y), one(rx.position.x), one(rx.position.y), [tx], [rx])
+        out = np.asarray(self.compute(view), dtype=np.float64).reshape(-1)
+        if out.size != 1 or not np.isfinite(out[0]):
+            raise ValueError('math domain error')          # what math.log10(0) raises in a per-object model (path_loss.py:66)
+        return float(out[0])
 
 
 def pl_constant_dB(carrier_freq_GHz: float, ple: float) -> float:

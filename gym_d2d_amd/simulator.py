@@ -20,7 +20,7 @@ from .devices import Devices
 from .envs.env_config import EnvConfig
 from .id import Id
 from .link_type import LinkType
-from .path_loss import PathLoss
+from .path_loss import ArrayPathLoss, PathLoss, PathLossView
 from .position import Position, get_random_position, get_random_position_nearby
 from .traffic_model import TrafficModel
 
@@ -130,7 +130,50 @@ class Simulator:
         if self._link_sig:
             self._evaluate_path_loss_table()
 
+    def _evaluate_array_path_loss(self) -> bool:
+        """ArrayPathLoss on a batch: compute(view) on the GPU, the [B,N,N] dB tensor handed over from device memory
+        (d2d_set_path_loss_link_table_dev).  False when torch / CUDA is not there (the host routes below then serve it)."""
+        try:
+            import torch
+        except Exception:       # pragma: no cover
+            return False
+        if not torch.cuda.is_available():
+            return False
+        h = self.handle
+        dev = torch.device('cuda', self.config.device_ordinal)
+        n = len(self.link_tx)
+        with torch.cuda.device(dev):
+            if self._pl_positions is not None:               # host-supplied positions, possibly float64: as given
+                p = torch.as_tensor(np.asarray(self._pl_positions), device=dev)
+                tx, rx = p[:, torch.as_tensor(self.link_tx.astype(np.int64), device=dev)], p[:, torch.as_tensor(self.link_rx.astype(np.int64), device=dev)]
+                cols = (tx[..., 0], tx[..., 1], rx[..., 0], rx[..., 1])
+            else:                                            # device-side reset: POS_X / POS_Y where they are, gathered per link by torch
+                def plane(which):
+                    ptr, _ = h.get_buffer(which)
+                    holder = type('Plane', (), {'__cuda_array_interface__': {'shape': (self.num_envs, len(self._dev_list)), 'typestr': '<f4',
+                                                                             'data': (ptr, False), 'version': 2, 'strides': None}})()
+                    return torch.as_tensor(holder, device=dev)
+                px, py = plane(_native.BUF_POS_X), plane(_native.BUF_POS_Y)
+                h.synchronize()                              # the sampler wrote them on the handle's stream; torch reads on its own
+                jt, jr = torch.as_tensor(self.link_tx.astype(np.int64), device=dev), torch.as_tensor(self.link_rx.astype(np.int64), device=dev)
+                cols = (px[:, jt], py[:, jt], px[:, jr], py[:, jr])
+            view = PathLossView(torch, *cols, [self._dev_list[i] for i in self.link_tx], [self._dev_list[i] for i in self.link_rx], like=cols[0])
+            pl = self.path_loss.compute(view)
+            if tuple(pl.shape) != (self.num_envs, n, n):
+                raise ValueError(f'ArrayPathLoss.compute must return [{self.num_envs},{n},{n}], got {tuple(pl.shape)}')
+            if pl.dtype not in (torch.float32, torch.float64):
+                pl = pl.double()
+            pl = pl.contiguous()
+            torch.cuda.current_stream(dev).synchronize()     # the conversion kernel runs on the handle's stream
+            h.set_path_loss_link_table_dev(pl.data_ptr(), _native.F64 if pl.dtype == torch.float64 else _native.F32, n, True)
+        return True
+
     def _evaluate_path_loss_table(self) -> None:
+        if len(self.link_tx) == 0:
+            return                                       # no links, no pairs: the next non-empty list evaluates them (ADVICE r5)
+        if self.num_envs > 1 and isinstance(self.path_loss, ArrayPathLoss) and self._evaluate_array_path_loss():
+            self._pl_covered = (set(self.link_tx.tolist()), set(self.link_rx.tolist()))
+            return
         txs, rxs = set(self.link_tx.tolist()), set(self.link_rx.tolist())
         if self.num_envs == 1:
             # one env: a [D,D] DEVICE table, which survives the link list changing from step to step (D2DEnv steps whatever
@@ -163,10 +206,11 @@ class Simulator:
         self._pl_covered = (txs, rxs)
 
     def fixed_positions(self):
-        """(mask[D] uint8, xy[D,2] float32) of devices pinned by the device_config_file (simulator.py:65-66)."""
+        """(mask[D] uint8, xy[D,2] float64) of devices pinned by the device_config_file (simulator.py:65-66), in the file's own
+        precision (JSON numbers are Python floats)."""
         d = len(self._dev_list)
         mask = np.zeros(d, dtype=np.uint8)
-        xy = np.zeros((d, 2), dtype=np.float32)
+        xy = np.zeros((d, 2), dtype=np.float64)
         for k, dev in enumerate(self._dev_list):
             if dev.id != BASE_STATION_ID and dev.id in self.config.devices:
                 mask[k] = 1
@@ -216,8 +260,9 @@ class Simulator:
         """Draw new device positions (simulator.py:61-75).
 
         B == 1: sampled on the host with Python's `random`, in the reference's device order, so `random.seed(k)`
-        gives the reference's layout; coordinates are rounded to float32 (what the GPU holds) before being stored on
-        the Device objects.  B > 1: sampled on the GPU (csrc/d2d_reset.hip)."""
+        gives the reference's layout - in the reference's precision: the Device objects hold the float64 coordinates and the
+        GPU gets them as (hi, lo) float32 pairs (d2d_set_positions_f64).  B > 1: sampled on the GPU in float32
+        (csrc/d2d_reset.hip)."""
         if self.num_envs == 1:
             self._reset_host()
         else:
@@ -236,18 +281,23 @@ class Simulator:
                 pos = get_random_position_nearby(self.config.cell_radius_m, anchor.position, self.config.d2d_radius_m)
             else:
                 raise ValueError(f'Invalid configuration for device "{device.id}".')
-            device.set_position(Position(float(np.float32(pos.x)), float(np.float32(pos.y))))
+            device.set_position(pos)
         self.push_positions()
 
     def push_positions(self) -> None:
         """Upload the Device objects' positions (B == 1) and refresh a host-evaluated path-loss table."""
-        xy = np.array([d.position.as_tuple() for d in self._dev_list], dtype=np.float32)
+        xy = np.array([d.position.as_tuple() for d in self._dev_list], dtype=np.float64)
         self.handle.set_positions(np.tile(xy[None, :, 0], (self.num_envs, 1)), np.tile(xy[None, :, 1], (self.num_envs, 1)))
         self._refresh_path_loss_table()
 
     def set_positions(self, positions: np.ndarray) -> None:
-        """positions [B, D, 2] (float32-representable) -> HBM; B == 1 also updates the Device objects."""
-        positions = np.asarray(positions, dtype=np.float32)
+        """positions [B, D, 2] -> HBM; B == 1 also updates the Device objects.  A float64 array is taken in the reference's own
+        precision (position.py:7-12; d2d_set_positions_f64: hi + lo float32 pairs on the device, differences exact to ~1e-7 -
+        when every value is float32-representable that is the float32 upload, same kernels, same bits); any other dtype is
+        uploaded as float32."""
+        positions = np.asarray(positions)
+        if positions.dtype != np.float64:
+            positions = positions.astype(np.float32)
         self.handle.set_positions(positions[..., 0], positions[..., 1])
         if self.num_envs == 1:
             for d, xy in zip(self._dev_list, positions[0]):
@@ -261,10 +311,17 @@ class Simulator:
         mask, xy = self.fixed_positions()
         if mask.any():
             self.handle.reset_positions(seed, episode, mask, xy)
+            if (xy != xy.astype(np.float32)).any():
+                # pinned coordinates that float32 cannot hold (a device_config_file the reference saved): the sampled layout comes
+                # back once, the pinned devices take the file's float64 values, and the whole goes up as (hi, lo) pairs
+                pos = self.positions().astype(np.float64)
+                pos[:, mask.astype(bool)] = xy[mask.astype(bool)]
+                self.handle.set_positions(pos[..., 0], pos[..., 1])
         else:
             self.handle.reset_positions(seed, episode)
         if self.num_envs == 1:
-            pos = self.positions()[0]
+            pos = self.positions()[0].astype(np.float64)
+            pos[mask.astype(bool)] = xy[mask.astype(bool)]
             for d, p in zip(self._dev_list, pos):
                 d.set_position(Position(float(p[0]), float(p[1])))
         self._refresh_path_loss_table()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 4      /* 4: D2D_ERR_NO_MEMORY, link-indexed path-loss table, measurement probes moved out (d2d_hip_diag.h) */
+#define D2D_ABI_VERSION 5      /* 5: float64 positions (d2d_set_positions_f64), device-resident path-loss table (d2d_set_path_loss_link_table_dev) */
 #define D2D_MAX_LINKS 2048      /* links per env the step kernel's LDS staging is sized for */
 #define D2D_UNIQUE_ID_BYTES 128 /* size of an RCCL unique id (ncclUniqueId)                  */
 
@@ -158,6 +158,14 @@ int d2d_set_path_loss_table(d2d_handle* h, const double* pl_db, int32_t per_env)
  * 4.3 GB instead of 9.7 GB per 4096 envs of 512 links).  A later d2d_set_links drops the table: the next
  * step then fails with D2D_ERR_STATE until a path-loss model is set again.                              */
 int d2d_set_path_loss_link_table(d2d_handle* h, const double* pl_db, int32_t n_links, int32_t per_env);
+/* The same table already RESIDENT ON THE DEVICE - what an array-native PathLoss plugin computes for a whole batch at once
+ * (gym_d2d_amd.path_loss.ArrayPathLoss.compute(view) -> pl_db[B,N,N]; a per-object PathLoss.__call__ over a batch is
+ * B x N x N Python calls, 1.1e9 at 4096 x 512).  pl_db_dev: device pointer, dtype D2D_F64 or D2D_F32 (float32 dB near 100 dB
+ * carry 3.8e-6 dB of their own: prefer float64), [N,N] (per_env = 0) or [B,N,N]; converted to linear gains by one streaming
+ * kernel (csrc/d2d_gain.hip: the exponential in double, rounded once) on the handle's stream - work that produced the table on
+ * ANOTHER stream must have finished.  Synchronous: the caller may free the table when the call returns.  A failed call leaves
+ * the handle without a path-loss table (the next step answers D2D_ERR_STATE), never with a partial one.                      */
+int d2d_set_path_loss_link_table_dev(d2d_handle* h, const void* pl_db_dev, int32_t dtype, int32_t n_links, int32_t per_env);
 
 /* Which (tx, rx) device pairs act this step and as what (Action.tx/rx/link_type, actions.py:9-15;
  * typing rule d2d_env.py:80-91).  n_links <= max_links.  Order = agent order of the outputs.       */
@@ -246,6 +254,19 @@ int d2d_upload(d2d_handle* h, int32_t which, const void* host_src, size_t bytes,
 int d2d_download(d2d_handle* h, int32_t which, void* host_dst, size_t bytes, size_t src_offset);
 /* Simulator.reset (simulator.py:61-75) with host-supplied positions: x,y [env_count, D] f32.       */
 int d2d_set_positions(d2d_handle* h, const float* x, const float* y, int32_t env_begin, int32_t env_count);
+
+/* The same in the REFERENCE'S OWN precision: Position holds Python floats (position.py:7-12), the samplers and a
+ * device_config_file produce float64 coordinates (position.py:18-45, simulator.py:61-75, d2d_env.py:124-134).  x, y
+ * [env_count, D] float64.  Each coordinate is kept as hi + lo, hi = the nearest float32 (what POS_X / POS_Y, LINK_POS, the obs
+ * table and D2D_BUF_OBS hold - the float32 rounding of the reference's value), lo = the float32 nearest to the remainder; the
+ * step then forms every tx - rx difference as (tx_hi - rx_hi) + (tx_lo - rx_lo), exact to ~1e-7 of the DIFFERENCE.  (float32
+ * coordinates carry 3e-5 m at 500 m: a receiver 0.1 m from its transmitter is then off by 3e-4 relative - 2e-5 on sinr_db,
+ * twice the 1e-5 bar, from input rounding alone.)  When every value is float32-representable the call is d2d_set_positions:
+ * same kernels, same bits.  Any other way of writing positions (d2d_set_positions on ALL envs, d2d_upload / d2d_bind_buffer of
+ * POS_X / POS_Y, d2d_reset_positions - whose sampler draws float32 coordinates -, d2d_positions_changed) returns the handle to
+ * float32 positions; d2d_set_positions on a sub-range keeps the other envs' low parts.  Costs one more 16-byte row per link and
+ * step and the one-link-per-thread kernels (4096 x 512: see DESIGN.md 4.1).                                                  */
+int d2d_set_positions_f64(d2d_handle* h, const double* x, const double* y, int32_t env_begin, int32_t env_count);
 
 /* The step kernel reads per-LINK position rows (tx_x, tx_y, rx_x, rx_y) that the library derives from
  * POS_X / POS_Y whenever it knows they changed (d2d_set_positions, d2d_upload, d2d_reset_positions,

@@ -41,6 +41,7 @@ int main(void) {
     EXPECT_ERR(d2d_set_path_loss_shadowing(NULL, 1, one, one, one, 1.0, 1.0, 1));
     EXPECT_ERR(d2d_set_path_loss_table(NULL, one, 0));
     EXPECT_ERR(d2d_set_path_loss_link_table(NULL, one, 1, 0));
+    EXPECT_ERR(d2d_set_path_loss_link_table_dev(NULL, one, D2D_F64, 1, 0));
     EXPECT_ERR(d2d_set_links(NULL, 1, ione, ione, ione));
     EXPECT_ERR(d2d_set_fixed_actions(NULL, 1, ione, ione, ione));
     EXPECT_ERR(d2d_positions_changed(NULL));
@@ -56,6 +57,7 @@ int main(void) {
     EXPECT_ERR(d2d_upload(NULL, 0, fone, 4, 0));
     EXPECT_ERR(d2d_download(NULL, 0, fone, 4, 0));
     EXPECT_ERR(d2d_set_positions(NULL, fone, fone, 0, 1));
+    EXPECT_ERR(d2d_set_positions_f64(NULL, one, one, 0, 1));
     EXPECT_ERR(d2d_reset_positions(NULL, 1, 0, mask, fone));
     EXPECT_ERR(d2d_set_env_offset(NULL, 0));
     EXPECT_ERR(d2d_step(NULL, NULL));
@@ -119,6 +121,11 @@ int main(void) {
     EXPECT_ERR(d2d_set_device_table(h, D, NULL, one, one, one, one));
     EXPECT_ERR(d2d_set_path_loss_power_law(h, D + 1, one, one, one));
     EXPECT_ERR(d2d_set_path_loss_table(h, NULL, 0));
+    EXPECT_ERR(d2d_set_path_loss_link_table_dev(h, NULL, D2D_F64, 1, 0));
+    EXPECT_ERR(d2d_set_path_loss_link_table_dev(h, one, 9, 1, 0));   /* unknown dtype */
+    EXPECT_ERR(d2d_set_path_loss_link_table_dev(h, one, D2D_F64, 1, 0));   /* before d2d_set_links */
+    EXPECT_ERR(d2d_set_positions_f64(h, NULL, one, 0, 1));
+    EXPECT_ERR(d2d_set_positions_f64(h, one, one, 0, 100000));       /* env range */
     { const int32_t tx[2] = {1, 9}, rx[2] = {0, 0}, ty[2] = {1, 1}; EXPECT_ERR(d2d_set_links(h, 2, tx, rx, ty)); }
     { const int32_t tx[2] = {1, 2}, rx[2] = {0, 0}, ty[2] = {1, 7}; EXPECT_ERR(d2d_set_links(h, 2, tx, rx, ty)); }
     EXPECT_ERR(d2d_set_links(h, 5000, ione, ione, ione));

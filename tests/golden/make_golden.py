@@ -15,7 +15,9 @@ rewards under all reward functions, obs rows).  No reference source travels.
 
 Positions are rounded to float32 BEFORE the reference computes anything from them, so the
 reference (fp64 arithmetic), the NumPy oracle and the fp32 HIP kernels all see identical
-inputs.
+inputs - except in the `case16_unrounded_*` cases, which keep the float64 layouts exactly as
+the reference's own reset() drew them (position.py:18-45): what a user of the reference has.
+The HIP path takes those through d2d_set_positions_f64 (hi + lo float32 pairs).
 """
 import json
 import os
@@ -265,12 +267,13 @@ def env_meta(env, pl):
     }
 
 
-def run_episode(gym, name, seed, env_config, pl, n_steps, *, extra_rewards=None, action_fn=None, raw_store=True):
+def run_episode(gym, name, seed, env_config, pl, n_steps, *, extra_rewards=None, action_fn=None, raw_store=True, round_pos=True):
     """reset() + n_steps step()s with all links acting; stores raw int actions per step."""
     seed_all(gym, seed)
     env = gym.make('D2DEnv-v0', env_config=dict(env_config))
     env.reset()
-    round_positions(env)
+    if round_pos:
+        round_positions(env)
     obs = recompute_after_reset(env)
     extra_rewards = extra_rewards or {}
     steps = [record_step(env, extra_rewards, obs)]
@@ -450,6 +453,29 @@ def main():
         steps.append(rec)
     save_case('case14_traffic_model', dict(env_meta(env, ld), seed=114, case='case14_traffic_model'),
               snapshot_devices(env), steps)
+
+    # (16) the reference's OWN float64 layouts, not rounded: cases 01, 03 and 07 again with the positions exactly as reset() drew
+    # them (position.py:18-45) resp. as save_device_config wrote them (d2d_env.py:124-134)
+    run_episode(gym, 'case16_unrounded_default', 101, {}, ld, 10, round_pos=False)
+    run_episode(gym, 'case16_unrounded_stress256', 103, {'num_rbs': 256, 'num_cues': 256, 'num_due_pairs': 256}, ld, 3, round_pos=False)
+    seed_all(gym, 107)
+    env = gym.make('D2DEnv-v0', env_config={'num_rbs': 8, 'num_cues': 6, 'num_due_pairs': 6})
+    env.reset()
+    tmp = Path(tempfile.mkdtemp()) / 'device_config.json'
+    env.save_device_config(tmp)
+    cfg_json = json.loads(tmp.read_text())
+    for dev_id in ('cue03', 'due04', 'due05', 'mbs'):
+        cfg_json[dev_id]['config'] = dict(cfg_json[dev_id]['config'])
+    cfg_json['cue03']['config'].update(tx_antenna_gain_dBi=2.5, body_loss_dB=1.0, thermal_noise_dBm=-101.0)
+    cfg_json['due04']['config'].update(ix_margin_dB=1.5, subcarrier_spacing_kHz=30)
+    cfg_json['due05']['config'].update(rx_antenna_gain_dBi=3.0, noise_figure_dB=5.0, sinr_dB=-6.0)
+    cfg_json['mbs']['config'].update(rx_antenna_gain_dBi=15.0, cable_loss_dB=3.0)
+    del cfg_json['cue01'], cfg_json['due02'], cfg_json['due03']      # these stay random at reset
+    tmp.write_text(json.dumps(cfg_json))
+    run_episode(gym, 'case16_unrounded_device_config', 1107,
+                {'num_rbs': 8, 'num_cues': 6, 'num_due_pairs': 6, 'device_config_file': tmp}, ld, 2, round_pos=False)
+    if len(sys.argv) == 1 or any(tag in 'case16_unrounded_device_config' for tag in sys.argv[1:]):
+        (HERE / 'case16_unrounded_device_config.json').write_text(json.dumps(cfg_json))
 
     # (15) the reference's own samplers - get_random_position / get_random_position_nearby (position.py:18-45) as driven
     # by Simulator.reset (simulator.py:61-75) - fed with the counter-based Philox uniforms the device-side reset

@@ -42,8 +42,8 @@ def env_config_for(case, **extra):
                              'due_min_tx_power_dBm', 'due_max_tx_power_dBm', 'cue_max_tx_power_dBm',
                              'mbs_max_tx_power_dBm', 'carrier_freq_GHz', 'num_subcarriers', 'subcarrier_spacing_kHz')}
     cfg['path_loss_model'] = path_loss_class(m)
-    if case.name == 'case07_device_config':
-        cfg['device_config_file'] = GOLDEN_DIR / 'case07_device_config.json'
+    if (GOLDEN_DIR / f'{case.name}.json').exists():       # cases 07 and 16_unrounded_device_config: the file the reference loaded
+        cfg['device_config_file'] = GOLDEN_DIR / f'{case.name}.json'
     cfg.update(extra)
     return cfg
 

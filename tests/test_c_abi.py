@@ -86,6 +86,6 @@ def test_release_library_exports_exactly_the_product_header():
     exported = {ln.split()[-1] for ln in nm.splitlines() if ' T d2d_' in ln}
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     assert set(_native.SIGNATURES) == declared
-    assert len(declared) <= 41          # 42 at ABI 3, three of them write probes
+    assert len(declared) == 43          # ABI 5: the 41 of ABI 4 + d2d_set_positions_f64 + d2d_set_path_loss_link_table_dev
     probe = subprocess.run(['nm', '-D', '--defined-only', str(LIB_DIR / 'libd2d_probe.so')], capture_output=True, text=True, check=True).stdout
     assert {ln.split()[-1] for ln in probe.splitlines() if ' T d2d_' in ln} == {'d2d_probe_write_variants', 'd2d_probe_write_staged', 'd2d_probe_last_error'}

@@ -147,7 +147,7 @@ def test_render_prints_observations(capsys):
 
 def test_host_reset_reproduces_python_random_stream():
     """random.seed(k) gives the layout the reference would draw (same consumption order: theta then radius; CUEs,
-    then per pair tx and the rx rejection loop - simulator.py:61-75), rounded to float32."""
+    then per pair tx and the rx rejection loop - simulator.py:61-75) - bit for bit, in float64: nothing is rounded."""
     from gym_d2d_amd.envs import D2DEnv
     env = D2DEnv({'num_cues': 3, 'num_due_pairs': 3})
     random.seed(12)
@@ -162,8 +162,7 @@ def test_host_reset_reproduces_python_random_stream():
 
     want = [(0.0, 0.0)] + [draw(500.0) for _ in range(3)]
     for _ in range(3):
-        # NB the rx anchor is the tx position AS STORED, i.e. already rounded to float32
-        tx = tuple(float(np.float32(v)) for v in draw(500.0))
+        tx = draw(500.0)
         want.append(tx)
         while True:
             dx, dy = draw(20.0)
@@ -171,7 +170,8 @@ def test_host_reset_reproduces_python_random_stream():
             if not x * x + y * y > 500.0 ** 2:
                 want.append((x, y))
                 break
-    assert np.array_equal(got, np.array(want, dtype=np.float32).astype(np.float64))
+    assert np.array_equal(got, np.array(want, dtype=np.float64))
+    assert (got != got.astype(np.float32)).any()
     env.simulator.handle.close()
 
 
@@ -208,9 +208,9 @@ def test_integration_md_binding_stub_runs_as_written():
     for d in devices.values():
         if d.id != 'mbs':
             r, th = 400.0 * math.sqrt(rng.random()), 2 * math.pi * rng.random()
-            d.set_position(Position(float(np.float32(r * math.cos(th))), float(np.float32(r * math.sin(th)))))
-    for tx, rx in devices.dues.values():                          # receivers near their transmitters
-        rx.set_position(Position(float(np.float32(tx.position.x + 7.0)), float(np.float32(tx.position.y - 5.0))))
+            d.set_position(Position(r * math.cos(th), r * math.sin(th)))      # Python floats, as the reference's reset leaves them
+    for tx, rx in devices.dues.values():                          # receivers near their transmitters (one of them 0.2 m away)
+        rx.set_position(Position(tx.position.x + (0.15 if tx.id == 'due00' else 7.0), tx.position.y - (0.1 if tx.id == 'due00' else 5.0)))
     core = ns['HipSimulatorCore'](config, devices, LogDistancePathLoss(config.carrier_freq_GHz))
     core.push_positions()
     acts = Actions()

@@ -621,3 +621,52 @@ def test_rollout_kernel_rare_paths_are_bit_identical(native, lpt, shape):
     assert rel_err(snaps['rollout']['BUF_SINR_DB'], ref['sinr_db']) <= TOL
     assert rel_err(snaps['rollout']['BUF_REWARD'][:, 0], ref['reward']) <= TOL
     h.close()
+
+
+@pytest.mark.parametrize('lpt', [1, 2])
+def test_rollout_kernel_zero_distance_own_link_matches_the_generic_kernels(native, lpt):
+    """A link whose transmitter and receiver coincide (1 / d^2: own term +inf): the rollout kernel opens its interference sum at
+    minus the own term, and -inf + inf would be NaN where the kernels that leave the own link out keep the interferers' finite
+    sum.  Any non-finite term sends the lane to the sorted sum, which excludes the own
+    entry: same bits as the mask walk and the all-pairs sweep, alone on its RB (env 0) and with company (env 1); an INTERFERER
+    on top of a receiver (env 2: accumulator inf, SINR -inf) likewise.  All three raise FLAG_ZERO_DISTANCE."""
+    rbs, cues, dues = 64, 128, 128
+    b = 4
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=123)
+    h = sim.handle
+    pc, pd = sim.config.num_pwr_actions['cue'], sim.config.num_pwr_actions['due']
+    levels = np.array([pc] * cues + [pd] * dues)
+    due_tx = lambda p: 1 + cues + 2 * p
+    due_rx = lambda p: 2 + cues + 2 * p
+
+    def alone(env, rb, links):
+        cur = raw[env] // levels
+        raw[env] = np.where(cur == rb, ((rb + 1) % rbs) * levels + raw[env] % levels, raw[env])
+        for l in links:
+            raw[env, l] = rb * levels[l] + 10
+    for env in (0, 1):
+        pos[env, due_rx(7)] = pos[env, due_tx(7)]
+    alone(0, 5, [cues + 7])
+    alone(1, 5, [cues + 7, cues + 30, 4])
+    pos[2, due_tx(11)] = pos[2, due_rx(3)]                    # an interferer exactly on a receiver
+    alone(2, 9, [cues + 3, cues + 11])
+    sim.set_positions(pos)
+    h.set_obs_mode(native.OBS_TABLE)
+    snaps = {}
+    for name, bucket, walk in (('mask_walk', True, 0), ('rollout', True, 2), ('all_pairs', False, 0)):
+        h.set_bucketing(bucket)
+        h.set_tuning(native.TUNE_STEP_WALK, walk)
+        h.set_tuning(native.TUNE_STEP_LPT, lpt if name == 'rollout' else -1)
+        sim.step_arrays(raw)
+        snaps[name] = _snapshot(sim, native)
+    _same(snaps)
+    got = snaps['rollout']
+    # (what the values ARE matters less than that every kernel produces the same ones: the Newton step of the SINR quotient turns
+    # inf / x and x / inf into NaN everywhere; the reference raises ValueError('math domain error') at such a layout, path_loss.py:66)
+    for env, link in ((0, cues + 7), (1, cues + 7), (2, cues + 3)):
+        assert not np.isfinite(got['BUF_SINR_DB'][env, link]), (env, got['BUF_SINR_DB'][env, link])
+    assert np.isfinite(got['BUF_SINR_DB'][1, cues + 30]) and np.isfinite(got['BUF_SINR_DB'][3]).all()
+    for env in (0, 1, 2):
+        assert got['BUF_ENV_FLAGS'][env] & native.FLAG_ZERO_DISTANCE
+    assert got['BUF_ENV_FLAGS'][3] == 0
+    h.close()

@@ -155,11 +155,12 @@ def test_reset_draws_positions_then_steps_with_all_links(stub):
     obs = env.reset()
     assert list(obs) == ['cue00:mbs', 'cue01:mbs', 'due00:due01', 'due02:due03']       # d2d_env.py:54-60
     x, y = h.last('positions')
-    assert x.shape == (1, 7) and x.dtype == np.float32 and x[0, 0] == 0 and y[0, 0] == 0
+    assert x.shape == (1, 7) and x.dtype == np.float64 and x[0, 0] == 0 and y[0, 0] == 0      # the reference's precision (position.py:7-12)
     assert (np.hypot(x, y) <= 100.0 + 1e-3).all()
     assert np.hypot(x[0, 3] - x[0, 4], y[0, 3] - y[0, 4]) <= 5.0 + 1e-3
     devs = list(env.simulator.devices.values())
-    assert [d.position.x for d in devs] == [float(v) for v in x[0]]        # objects hold what the GPU holds
+    assert [d.position.x for d in devs] == [float(v) for v in x[0]]        # objects hold what the GPU is given (hi + lo pairs)
+    assert any(float(np.float32(v)) != v for v in x[0, 1:])                # ... and that is NOT rounded to float32
     rb, pw = h.uploads[_native.BUF_RB][0], h.uploads[_native.BUF_PWR][0]
     assert (rb >= 0).all() and (rb < 25).all() and (pw[:2] <= 23).all() and (pw[2:] <= 20).all()
 

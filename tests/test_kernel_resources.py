@@ -28,7 +28,7 @@ def kernels(tmp_path_factory):
     out = {}
     for blk in re.split(r'\n  - ', asm[asm.find('amdhsa.kernels'):]):
         name = re.search(r'\.name:\s+(\S+)', blk)
-        m = name and re.match(r'_ZN3d2d11step_kernelILi(\d)ELi(\d)ELb([01])ELi(\d)ELi(\d)EEEvNS_8StepArgsE', name.group(1))
+        m = name and re.match(r'_ZN3d2d11step_kernelILi(\d)ELi(\d)ELb([01])ELi(\d)ELi(\d+)EEEvNS_8StepArgsE', name.group(1))
         if not m:
             continue
         field = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, blk).group(1))
@@ -60,7 +60,9 @@ def test_strided_and_shadowing_kernels_stay_within_a_few_lane_spills(kernels):
     per pair, inlined at every pair evaluation) keep a few scalars in VGPR lanes - never in memory."""
     for (mode, lpt, full, hot, opt), k in kernels.items():
         if mode == 3:
-            assert k['sgpr_spills'] < 80, ((mode, lpt, full, hot, opt), k)
+            # (round 6: the Box-Muller behind every shadowed pair grew a log1p arm and an exact-quadrant cosine; the strided
+            # exact-position variant - the coldest kernel in the library - keeps 93 scalars in lanes, still none in memory)
+            assert k['sgpr_spills'] < (100 if opt & 16 else 80), ((mode, lpt, full, hot, opt), k)
         elif lpt == 0:
             assert k['sgpr_spills'] < 32, ((mode, lpt, full, hot, opt), k)
 
@@ -82,7 +84,8 @@ def rollout_kernels(tmp_path_factory):
             out[tuple(int(x) for x in m.groups())] = {'vgpr': field('vgpr_count'), 'sgpr_spills': field('sgpr_spill_count'),
                                                       'vgpr_spills': field('vgpr_spill_count'), 'scratch': field('private_segment_fixed_size'),
                                                       'static_lds': field('group_segment_fixed_size')}
-    assert len(out) == 20, sorted(out)             # 2 path-loss modes x (4 option sets x 2 links per thread + 2 padded variants)
+    # 2 path-loss modes x (4 option sets x 2 links per thread + 2 padded variants + 6 exact-position variants: option bit 16)
+    assert len(out) == 32, sorted(out)
     return out
 
 
@@ -92,7 +95,9 @@ def test_rollout_kernel_of_round5_keeps_full_occupancy_and_no_static_lds(rollout
     the dynamic block (the kernel addresses LDS by raw byte offsets)."""
     for key, k in rollout_kernels.items():
         assert k['scratch'] == 0 and k['vgpr_spills'] == 0 and k['sgpr_spills'] == 0 and k['static_lds'] == 0, (key, k)
-        if key[1] & 10:                                  # scalar records (2) or a padded link count (8: one link per thread)
+        if key[1] & 16:                                  # exact positions (d2d_set_positions_f64): a fourth 16-byte row per link
+            assert k['vgpr'] <= 80, (key, k)             # 6 waves per SIMD
+        elif key[1] & 10:                                # scalar records (2) or a padded link count (8: one link per thread)
             assert k['vgpr'] <= 64, (key, k)
 
 

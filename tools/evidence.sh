@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the round's evidence on ONE GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 3000 -- 'bash tools/evidence.sh r5'
+#   gpurun --timeout 3000 -- 'bash tools/evidence.sh r6'
 # What it leaves under gpurun_out/<tag>_evidence/ (the only directory gpurun brings back): profiles/<tag>_kernel_stats_*.csv,
 # profiles/<tag>_pmc_*.json (rocprofv3 kernel trace and PMC passes, collected in SEPARATE runs, stamped with the digest of the
 # kernel sources), profiles/<tag>_bench_lines.jsonl (the driver-like default line and the stand-alone configurations), the GPU
 # suite's log.  Then, here:  cp gpurun_out/<tag>_evidence/profiles/* profiles/
-tag=${1:-r5}
+tag=${1:-r6}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${tag}_evidence; mkdir -p $O; cd $R
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/tests.log 2>&1; echo "gpu tests rc=$? $(tail -1 $O/tests.log)" > $O/summary.txt
 # rocprofv3 first: kernel trace + PMC passes per workload (tools/profile_bench.sh); bench.py quotes `roofline.traffic` from the
@@ -17,10 +17,14 @@ bash tools/profile_bench.sh $tag stress table 1000 > $O/prof_stress_table_export
 bash tools/profile_bench.sh $tag stress none 1000 --no-export --reward-per-env > $O/prof_stress_none.log 2>&1
 bash tools/profile_bench.sh $tag default linear 4000 > $O/prof_default_linear.log 2>&1
 bash tools/profile_bench.sh $tag plugin table 1000 > $O/prof_plugin_table.log 2>&1
+# the power-law kernels (COST-Hata: an exponent other than 2), obs-less and with the compact table
+bash tools/profile_bench.sh $tag hata none 1000 --no-export --reward-per-env > $O/prof_hata_none.log 2>&1
+bash tools/profile_bench.sh $tag hata table 1000 --no-export > $O/prof_hata_table.log 2>&1
 # the driver-like line (headline + core_mode + other_workloads + flat scalars), then the stand-alone configurations
 : > profiles/${tag}_bench_lines.jsonl
 for args in "" "--workload default" "--workload plugin" "--obs table --no-export" "--obs table" \
-            "--obs none --no-export --reward-per-env" "--obs-dtype float64 --steps 30"; do
+            "--obs none --no-export --reward-per-env" "--obs-dtype float64 --steps 30" \
+            "--workload hata --obs none --no-export --reward-per-env" "--workload hata --obs table --no-export"; do
   extra="--no-cpu-baseline --no-single-env-latency --no-extras"; [ -z "$args" ] && extra=""
   timeout 1200 python bench.py $args $extra 2>> $O/bench.err | tail -1 >> profiles/${tag}_bench_lines.jsonl
 done
