@@ -106,6 +106,7 @@ struct d2d_handle {
     int obs_mode = D2D_OBS_LINEAR;
     int bucketing = 1;
     int export_actions = 1;                          // d2d_step writes the decoded (rb, pwr) to D2D_BUF_RB / D2D_BUF_PWR
+    int pow_k = 0;                                   // PL_POWK: the integer every link transmitter's exponent lies within 1/2 of (refresh_tables)
     int obs_f64 = 0;                                 // D2D_BUF_OBS holds float64 (d2d_set_obs_dtype)
     int reward_layout = D2D_REWARD_PER_AGENT;        // SystemCapacity: [B,N] rows or one scalar per env (D2D_BUF_REWARD_ENV)
     int tune_rows = 0, tune_nt = 1, tune_xcd = 1, tune_block = 0, tune_variant = 0, tune_step_threads = 0, tune_stagger = 0;
@@ -185,7 +186,20 @@ int refresh_tables(d2d_handle* h) {
         cols[6 * D + d] = h->mode == d2d::PL_TABLE ? 2.0f : (float)h->expo[d];
         if (h->mode != d2d::PL_TABLE && h->expo[d] != 2.0) all_two = false;
     }
-    if (h->mode != d2d::PL_TABLE && h->mode != d2d::PL_SHADOW) h->mode = all_two ? d2d::PL_INV_SQUARE : d2d::PL_POWER;
+    if (h->mode != d2d::PL_TABLE && h->mode != d2d::PL_SHADOW) {
+        h->mode = all_two ? d2d::PL_INV_SQUARE : d2d::PL_POWER;
+        // PL_POWK: the exponents of the transmitters of the CURRENT links all lie within 1/2 of one integer k in 1 .. 8 (COST-Hata's
+        // 3.6 / 4.375, a log-distance ple of 3.5: k = 4) - then (d^2)^(-n/2) = (d^2)^(-k/2) (d^2)^phi with |phi| <= 1/4, and the
+        // kernels evaluate it with reciprocals, products and one short exp2(phi log2 d^2) (pow_k_gains); any other mix of exponents
+        // keeps the general split (pow_neg_half)
+        h->pow_k = 0;
+        if (!all_two && h->N > 0) {
+            const int k = (int)std::lround(h->expo[h->host_tx[0]]);
+            bool ok = k >= 1 && k <= 8;
+            for (int i = 0; i < h->N && ok; ++i) ok = std::fabs(h->expo[h->host_tx[i]] - (double)k) <= 0.5;
+            if (ok) { h->mode = d2d::PL_POWK; h->pow_k = k; }
+        }
+    }
     // Per-link records, 3 rows of [Nmax] x 16 B (layout: d2d_internal.h).  tx-side columns by the link's tx device,
     // rx-side by its rx device, so the kernel reads them coalesced by link index with no link -> device -> column
     // double hop; a link with a fixed action carries (rb, pwr) here, the others their column in the action array.
@@ -229,6 +243,11 @@ int refresh_tables(d2d_handle* h) {
     // rounding (6e-8 as a float, amplified by ln(d^2) e / 2 in (d^2)^(-e/2): 1.2e-6 at 300 m, e = 3.5) leaves the result
     std::vector<float> rech((size_t)2 * S, 0.0f);
     for (int i = 0; i < N; ++i) {
+        if (h->mode == d2d::PL_POWK) {                        // (phi, 0): the exponent's distance from k, halved
+            rech[2 * i] = (float)(-0.5 * (h->expo[h->host_tx[i]] - (double)h->pow_k));
+            rech[2 * i + 1] = 0.0f;
+            continue;
+        }
         const double hd = h->mode == d2d::PL_TABLE ? -1.0 : -0.5 * h->expo[h->host_tx[i]];
         float head = (float)hd;
         uint32_t hb;
@@ -450,6 +469,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     // (profiles/r5_rollout_nt_and_links_per_thread.jsonl)
     s.nt_results = h->tune_step_nt > 0 && h->obs_mode != D2D_OBS_LINEAR;
     s.rec_uniform = h->rec_uniform && h->tune_step_srec != 0;
+    s.pow_k = h->pow_k;
     s.ablate = h->tune_step_ablate;
     s.dbg = nullptr;
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
@@ -473,7 +493,7 @@ int run_step(d2d_handle* h, int action_mode, const int32_t* a0, const int32_t* a
     const bool rollout_cfg = action_mode == 0 && (h->n_fixed == 0 || (h->n_fixed < N && h->col_mode == 0)) && h->bucketing &&   // fixed links: a prefix
                              (h->reward_fn == D2D_REWARD_SYSTEM_CAPACITY || h->reward_fn == D2D_REWARD_SHANNON ||
                               h->reward_fn == D2D_REWARD_CUE_SINR_SHANNON) &&
-                             !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER) && (h->tune_step_ablate & ~8192) == 0 &&
+                             !will_fuse && (h->mode == d2d::PL_INV_SQUARE || h->mode == d2d::PL_POWER || h->mode == d2d::PL_POWK) && (h->tune_step_ablate & ~8192) == 0 &&
                              h->tune_step_prefetch != 0 && h->tune_step_threads == 0 && h->tune_step_epw <= 1 && h->tune_step_block == 0 &&
                              (N % 64 == 0 || N > 64) && N <= 1024;       // (no multiple of 64: padded; measured from 80 links up)
     const bool lists_pay = lists_can_help && (N > 1024 || h->obs_mode == D2D_OBS_NONE || rollout_cfg);

@@ -10,7 +10,11 @@ enum PlMode : int {
     PL_INV_SQUARE = 0,   // every exponent == 2 (LogDistance default / FreeSpace): gain = k / d^2, one v_rcp
     PL_POWER = 1,        // per-tx exponent (ple != 2, COST-Hata): gain = k * (d^2)^(-e/2)
     PL_TABLE = 2,        // host-evaluated [D,D] (or [B,D,D]) linear gain table
-    PL_SHADOW = 3        // PL_POWER + log-normal shadowing beyond d0, fresh Philox Gaussian per evaluation
+    PL_SHADOW = 3,       // PL_POWER + log-normal shadowing beyond d0, fresh Philox Gaussian per evaluation
+    PL_POWK = 4          // PL_POWER where the exponent of every link's transmitter lies within 1/2 of ONE integer k (StepArgs::pow_k;
+                         // COST-Hata's 3.6 / 4.375: k = 4): gain = (d^2)^(-k/2) by reciprocals and products, times (d^2)^phi,
+                         // phi = -(n - k) / 2 in [-1/4, 1/4] - three transcendentals and four products per pair instead of the
+                         // general split's two and fourteen (pow_k_gains, d2d_step_device.h)
 };
 
 // Per-link record, three 16-byte rows shared by all envs and read coalesced by link index (L2-resident).  Built on
@@ -55,6 +59,7 @@ struct StepArgs {
     int reward_fn;
     float reward_param;
     int write_table;
+    int pow_k;               // PL_POWK: the common integer k of the transmitters' exponents (1 .. 8); rec_h then holds (phi, 0)
     int rec_uniform;         // every aligned group of 64 links has identical records (device ids aside): scalar record loads
     int nt_results;          // nontemporal result stores (nothing re-reads them from L2 right behind this launch)
     int ablate;              // DIAGNOSTIC builds only (-DD2D_STEP_ABLATE=1): skip parts of the kernel to time the rest

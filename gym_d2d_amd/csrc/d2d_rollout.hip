@@ -66,7 +66,9 @@ namespace d2d {
 void rollout_lds_layout(int N, int R, int mode, int reward_fn, int xpos, StepLds* out) {
     std::memset(out, 0, sizeof(*out));
     unsigned off = LDS_HEAD_BYTES + ((unsigned)N + 1u) * 16u;
-    out->expo = off; if (mode == PL_POWER) off += ((unsigned)N + 1u) * 8u;
+    out->expo = off;
+    if (mode == PL_POWER) off += ((unsigned)N + 1u) * 8u;
+    else if (mode == PL_POWK) off += (((unsigned)N + 1u) * 4u + 7u) & ~7u;       // PL_POWK: the links' RBs (the tuple's fourth word holds phi)
     out->lo = off; if (xpos) off += ((unsigned)N + 1u) * 8u;      // exact positions: low parts of (tx_x, tx_y), + one for the stand-in
     off = (off + 15u) & ~15u;
     out->lists = off; off += ((unsigned)R + 1u) * 16u + (((unsigned)R + 1u + 3u) & ~3u) * 4u;
@@ -97,7 +99,11 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     static_assert(!PAD || (LPT == 1 && !SREC), "a link count that is no multiple of 64: one link per thread, per-lane records");
     static_assert(!XPOS || LPT == 1, "exact positions: one link per thread");
     constexpr bool POWLAW = MODE == PL_POWER;
-    static_assert(MODE == PL_INV_SQUARE || MODE == PL_POWER, "the rollout kernel serves the power laws");
+    // PL_POWK (one integer k within 1/2 of every transmitter's exponent, pow_k_gains): the tuple's fourth word is the transmitter's
+    // phi instead of its RB - no second LDS read per pair - and the RBs, which only the rare sweeps look at, sit in an array of their own
+    constexpr bool POWK = MODE == PL_POWK;
+    constexpr bool NF_ONLY = MODE != PL_POWER;                   // a zero distance shows as a non-finite gain: no smallest-distance tracking
+    static_assert(MODE == PL_INV_SQUARE || MODE == PL_POWER || MODE == PL_POWK, "the rollout kernel serves the power laws");
     static_assert(LPT == 1 || LPT == 2, "one or two links per thread");
     const int N = a.N, R = a.R, TPE = a.tpe;                     // N == LPT * TPE == LPT * blockDim.x; thread t: links LPT * t + u
     const int tid = threadIdx.x, b = (int)blockIdx.x;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     const bool shannon_reward = a.reward_fn == 2;                // link, looks at the other members of the RB: one link per thread only)
     const bool cue_sinr_reward = LPT == 1 && a.reward_fn == 3;
     const unsigned EMPTY = (unsigned)N * 16u;                    // byte offset of the stand-in tuple link[N]
-    const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_LO = a.lds.lo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
+    const unsigned L_LINK = LDS_HEAD_BYTES, L_EXPO = a.lds.expo, L_RB = a.lds.expo, L_LO = a.lds.lo, L_SLOTS = a.lds.lists, L_CNT = a.lds.lists + ((unsigned)R + 1u) * 16u;
     const unsigned L_POOL = a.lds.pool, L_FLAGS = 64u, L_DUMP = 60u, L_RED = a.lds.aux, L_LOW = a.lds.rx;
 
     RO_STAMP(0);
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         } else {
             // (per-lane records: a PREFIX of the links may carry fixed actions - traffic-model CUEs, traffic_model.py:15-32 - and the
             // action array then has a column per remaining link only)
-            in[u] = load_link(a, row, act_row, i, 0, 0, false, false, POWLAW, XPOS);
+            in[u] = load_link(a, row, act_row, i, 0, 0, false, false, POWLAW || POWK, XPOS);
         }
     }
 
@@ -154,8 +160,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             for (int k = tid + 2 * TPE; k < nl; k += TPE) { const unsigned f = k < rows ? e2 : 0u; lds_put<u32x4>(L_SLOTS + (unsigned)k * 16u, u32x4{f, f, f, f}); }
         }
         if (tid == TPE - 1) {
-            lds_put<f32x4>(L_LINK + EMPTY, f32x4{1.0e18f, 1.0e18f, -0.0f, __int_as_float(-1)});
+            lds_put<f32x4>(L_LINK + EMPTY, f32x4{1.0e18f, 1.0e18f, -0.0f, POWK ? 0.0f : __int_as_float(-1)});
             if (POWLAW) lds_put<f32x2>(L_EXPO + (EMPTY >> 1), f32x2{-1.0f, 0.0f});
+            if (POWK) lds_put<int>(L_RB + (EMPTY >> 2), -1);
             if (XPOS) lds_put<f32x2>(L_LO + (EMPTY >> 1), f32x2{0.0f, 0.0f});
         }
         if (tid < 5) lds_put<u32x4>((unsigned)tid * 16u, u32x4{0u, 0u, 0u, 0u});          // sum, dump, flags[4]: 80 bytes
@@ -215,8 +222,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // the tuple as two 8-byte halves (one ds_write2_b64): (x, y) goes out of the position row's own registers instead of being
         // copied into a fresh four-register tuple first
         lds_put<f32x2>(L_LINK + my_off, f32x2{in[u].pos.x, in[u].pos.y});
-        lds_put<f32x2>(L_LINK + my_off + 8u, f32x2{pz[u], __int_as_float(rb[u])});
+        lds_put<f32x2>(L_LINK + my_off + 8u, f32x2{pz[u], POWK ? in[u].hh.x : __int_as_float(rb[u])});
         if (POWLAW) lds_put<f32x2>(L_EXPO + (my_off >> 1), f32x2{in[u].hh.x, in[u].hh.y});
+        if (POWK) lds_put<int>(L_RB + (my_off >> 2), rb[u]);
         if (XPOS) lds_put<f32x2>(L_LO + (my_off >> 1), f32x2{in[u].plo.x, in[u].plo.y});
         pwr[u] = pw;
         row_off[u] = L_SLOTS + rbc * 16u;
@@ -276,10 +284,12 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             float dx = o.x - rx.x, dy = o.y - rx.y;
             if (XPOS) { const float2 l = lds_f2(L_LO + (e >> 1)); dx = coord_diff(o.x, rx.x, l.x, rxlo.x); dy = coord_diff(o.y, rx.y, l.y, rxlo.y); }
             const float d2 = fmaf(dx, dx, dy * dy);
-            const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (e >> 1)) : make_float2(-1.0f, 0.0f));
+            const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + (e >> 1)) : make_float2(POWK ? o.w : -1.0f, 0.0f), a.pow_k);
             if (POWLAW) dmin_ = min(dmin_, __float_as_int(d2));
             return o.z * g;
         };
+        // the RB of link j as the sweeps see it
+        const auto rb_of = [&](unsigned j, const f32x4& o) { return POWK ? lds_get<int>(L_RB + (j << 2)) : __float_as_int(o.w); };
         // the masked all-pairs sweep in ascending link order: the reference's own loop (simulator.py:95-101), the order every
         // other search variant reproduces; what a lane falls back to when nothing cheaper is exact
         const auto sweep = [&](int& dmin_) {
@@ -287,11 +297,11 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             COLD_LOOP
             for (int j = 0; j < N; ++j) {
                 const f32x4 o = lds_get<f32x4>(L_LINK + ((unsigned)j << 4));
-                const bool same = (__float_as_int(o.w) == rb[u]) & (j != i);
+                const bool same = (rb_of((unsigned)j, o) == rb[u]) & (j != i);
                 float dx = o.x - rx.x, dy = o.y - rx.y;
                 if (XPOS) { const float2 l = lds_f2(L_LO + ((unsigned)j << 3)); dx = coord_diff(o.x, rx.x, l.x, rxlo.x); dy = coord_diff(o.y, rx.y, l.y, rxlo.y); }
                 const float d2 = fmaf(dx, dx, dy * dy);
-                const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + ((unsigned)j << 3)) : make_float2(-1.0f, 0.0f));
+                const float g = pair_gain<MODE>(d2, POWLAW ? lds_f2(L_EXPO + ((unsigned)j << 3)) : make_float2(POWK ? o.w : -1.0f, 0.0f), a.pow_k);
                 if (POWLAW) dmin_ = same ? min(dmin_, __float_as_int(d2)) : dmin_;
                 s += same ? (double)(o.z * g) : 0.0;
             }
@@ -304,7 +314,12 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             const float dx = XPOS ? coord_diff(in[u].pos.x, rx.x, in[u].plo.x, rxlo.x) : in[u].pos.x - rx.x;
             const float dy = XPOS ? coord_diff(in[u].pos.y, rx.y, in[u].plo.y, rxlo.y) : in[u].pos.y - rx.y;
             d2_own = fmaf(dx, dx, dy * dy);
-            g_own = pair_gain<MODE>(d2_own, in[u].hh);
+            if (POWK) {
+                const float d[1] = {d2_own}, f[1] = {in[u].hh.x};
+                float g[1];
+                if (LIKELY(a.pow_k == 4)) pow_k_gains<1, 4>(d, f, 4, g); else pow_k_gains<1>(d, f, a.pow_k, g);
+                g_own = g[0];
+            } else g_own = pair_gain<MODE>(d2_own, in[u].hh, a.pow_k);
         }
 
         // ---- pass 2: the RB's eight slots in one read, every slot a tuple address
@@ -325,6 +340,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // underflow - makes the minimum 0 and sends the lane to the sorted sum: conservative.)
         int tmax = 0;
         unsigned tmin = 0xFFFFFFFFu;
+        unsigned members = 0u;                                   // links on my RB, read only when its row is full
 #define RO_PAIR(k, o)                                                                                                   \
         {                                                                                                               \
             f32x2 dd = f32x2{(o).x, (o).y} - rxv;                     /* one v_pk_add_f32: (x, y) sit in adjacent registers */ \
@@ -336,7 +352,46 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             acc += (double)t;                                                                                           \
             tmax = max(tmax, __float_as_int(t)); tmin = min(tmin, __float_as_uint(t));                                  \
         }
-        if (POWLAW) {
+        if (POWK) {
+            // three pairs at once, twice: squared distances, then pow_k_gains - the reciprocals, logarithms and exponentials of a group in
+            // flight together, the k-dependent products behind ONE uniform branch per group instead of one per pair (six at once: 68 VGPRs)
+#define RO_POWK_GROUP(KC, NP, FIRST, ...)                                                                               \
+            {                                                                                                           \
+                const f32x4* const os[NP] = {__VA_ARGS__};                                                              \
+                float d2v[NP], phv[NP], gv[NP];                                                                         \
+                _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                                        \
+                    f32x2 dd = f32x2{os[q]->x, os[q]->y} - rxv;                                                         \
+                    if (XPOS) dd = dd + (lds_get<f32x2>(L_LO + (off[FIRST + q] >> 1)) - rxlov);                         \
+                    d2v[q] = fmaf(dd.x, dd.x, dd.y * dd.y);                                                             \
+                    phv[q] = os[q]->w;                                                                                  \
+                }                                                                                                       \
+                pow_k_gains<NP, KC>(d2v, phv, a.pow_k, gv);                                                             \
+                _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                                        \
+                    const float t = os[q]->z * gv[q];                                                                   \
+                    acc += (double)t;                                                                                   \
+                    tmax = max(tmax, __float_as_int(t)); tmin = min(tmin, __float_as_uint(t));                          \
+                }                                                                                                       \
+            }
+#define RO_POWK_ALL(KC)                                                                                                 \
+            {                                                                                                           \
+                {                                                                                                       \
+                    const f32x4 o0 = lds_get<f32x4>(L_LINK + off[0]), o1 = lds_get<f32x4>(L_LINK + off[1]), o2 = lds_get<f32x4>(L_LINK + off[2]); \
+                    RO_POWK_GROUP(KC, 3, 0, &o0, &o1, &o2)                                                              \
+                }                                                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                {                                                                                                       \
+                    const f32x4 o3 = lds_get<f32x4>(L_LINK + off[3]), o4 = lds_get<f32x4>(L_LINK + off[4]), o5 = lds_get<f32x4>(L_LINK + off[5]); \
+                    RO_POWK_GROUP(KC, 3, 3, &o3, &o4, &o5)                                                              \
+                }                                                                                                       \
+                if (__builtin_amdgcn_ballot_w64(off[6] != EMPTY) != 0ull) {                                             \
+                    const f32x4 o6 = lds_get<f32x4>(L_LINK + off[6]), o7 = lds_get<f32x4>(L_LINK + off[7]);             \
+                    if (off[7] != EMPTY) members = lds_get<unsigned>(L_CNT + rbc * 4u);                                 \
+                    RO_POWK_GROUP(KC, 2, 6, &o6, &o7)                                                                   \
+                }                                                                                                       \
+            }
+            // ONE branch on k for the link: the common case (COST-Hata, ple 3.5 - 4.5) runs a copy without the tests on k
+            if (LIKELY(a.pow_k == 4)) RO_POWK_ALL(4) else RO_POWK_ALL(0)
+        } else if (POWLAW) {
             // (the power law's pairs carry an exponent pair each and a longer evaluation: three and three in flight - six take the
             // two-link kernel to 73 VGPRs = 6 waves per SIMD, and measured slower with one link too: COST-Hata obs-less 33.9 -> 32.0 us)
             {
@@ -357,14 +412,15 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             asm volatile("" ::"v"(o0.w), "v"(o1.w), "v"(o2.w), "v"(o3.w), "v"(o4.w), "v"(o5.w));   // .w kept live: ds_read_b128, not b96
         }
         // slots fill in arrival order: a seventh / eighth member exists for some lane of 2 in 3 / 1 in 4 waves
-        unsigned members = 0u;                                   // links on my RB, read only when its row is full
-        if (__builtin_amdgcn_ballot_w64(off[6] != EMPTY) != 0ull) {
+        if (!POWK && __builtin_amdgcn_ballot_w64(off[6] != EMPTY) != 0ull) {
             const f32x4 o6 = lds_get<f32x4>(L_LINK + off[6]), o7 = lds_get<f32x4>(L_LINK + off[7]);
             if (off[7] != EMPTY) members = lds_get<unsigned>(L_CNT + rbc * 4u);
             RO_PAIR(6, o6) RO_PAIR(7, o7)
             asm volatile("" ::"v"(o6.w), "v"(o7.w));
         }
 #undef RO_PAIR
+#undef RO_POWK_GROUP
+#undef RO_POWK_ALL
         // all partial sums exact <=> the sum is the ascending-order sum: largest and smallest non-zero term within 2^25
         // (nine values of 24 bits inside the 53 of a double); compared on the raw bits (conservative by less than one binade)
         // ... and a non-finite OWN term (transmitter and receiver in one place under 1 / d^2: inf) cannot be taken back out of the sum
@@ -462,7 +518,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         // per link, in here: the value would otherwise stay live across the other link's evaluation - a 65th VGPR.)
         if (shannon_reward) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = sinr_db >= a.reward_param ? sh : -1.0f;
         if (LPT == 1) sh_kept = sh;
-        const bool nonfinite = MODE == PL_INV_SQUARE ? !(fabsf(sinr_db) <= 3.0e38f) : (dmin == 0 || !(fabsf(sinr_db) <= 3.0e38f));
+        const bool nonfinite = NF_ONLY ? !(fabsf(sinr_db) <= 3.0e38f) : (dmin == 0 || !(fabsf(sinr_db) <= 3.0e38f));
         const bool huge = !(cap <= 3.0e7f);
         if (UNLIKELY(__builtin_amdgcn_ballot_w64(rule | nonfinite | huge) != 0ull)) {
             if (rule) {
@@ -471,7 +527,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
                 if (oor[u]) {
                     COLD_LOOP
                     for (int k = 0; k < N; ++k)
-                        hit |= (k != i) & sidelink((unsigned)k) & (__float_as_int(lds_get<f32x4>(L_LINK + ((unsigned)k << 4)).w) == rb[u]);
+                        hit |= (k != i) & sidelink((unsigned)k) & (rb_of((unsigned)k, lds_get<f32x4>(L_LINK + ((unsigned)k << 4))) == rb[u]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < RO_SLOTS; ++k)
@@ -488,7 +544,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
                 if (hit) lds_atomic_or(L_FLAGS + 4u, 1);
             }
             int my_flags = 0;
-            if (MODE == PL_INV_SQUARE) {
+            if (NF_ONLY) {
                 // 1 / d^2 gains: a zero distance (own link: signal inf; an interferer: accumulator inf) always ends in a non-finite SINR
                 if (nonfinite) { my_flags |= FLAG_NON_FINITE; if (d2_own == 0.0f || !(accf <= 3.0e38f)) my_flags |= FLAG_ZERO_DISTANCE; }
             } else {
@@ -518,7 +574,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         if (oor[0]) {
             COLD_LOOP
             for (int k = 0; k < N; ++k)
-                low |= (k != i) & (__float_as_int(lds_get<f32x4>(L_LINK + ((unsigned)k << 4)).w) == rb[0]) ? lds_get<int>(L_LOW + ((unsigned)k << 2)) : 0;
+                low |= (k != i) & ((POWK ? lds_get<int>(L_RB + ((unsigned)k << 2)) : __float_as_int(lds_get<f32x4>(L_LINK + ((unsigned)k << 4)).w)) == rb[0]) ? lds_get<int>(L_LOW + ((unsigned)k << 2)) : 0;
         } else {
             const u32x4 ml = lds_get<u32x4>(L_SLOTS + (unsigned)rb[0] * 16u);
             const unsigned o[RO_SLOTS] = {ml.x & 0xFFFFu, ml.x >> 16, ml.y & 0xFFFFu, ml.y >> 16, ml.z & 0xFFFFu, ml.z >> 16, ml.w & 0xFFFFu, ml.w >> 16};
@@ -694,7 +750,7 @@ hipError_t launch_rollout(const StepArgs& a, PlMode mode, int opt, int block_thr
         else if (opt & OPT_PAD) { if (opt & OPT_NT) D2D_RO_1(M, OPT_PAD | OPT_NT, 1); else D2D_RO_1(M, OPT_PAD, 1); }  \
         else if (a.lpt == 2) { D2D_RO_L(M, 2) } else { D2D_RO_L(M, 1) }                                  \
     } while (0)
-    if (mode == PL_INV_SQUARE) D2D_RO(PL_INV_SQUARE); else D2D_RO(PL_POWER);
+    if (mode == PL_INV_SQUARE) D2D_RO(PL_INV_SQUARE); else if (mode == PL_POWK) D2D_RO(PL_POWK); else D2D_RO(PL_POWER);
 #undef D2D_RO
 #undef D2D_RO_X
 #undef D2D_RO_L

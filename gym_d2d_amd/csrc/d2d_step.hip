@@ -57,7 +57,7 @@ void step_lds_layout(int N, int R, int mask_words, int fuse_obs, int lpt, int re
     out->rx = off; if (lpt == 0) off += (unsigned)N * 8u;
     out->sinr = off; out->sh = off + (unsigned)N * 4u; if (reward_fn >= 2) off += (unsigned)N * 8u;
     off = (off + 7u) & ~7u;
-    out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW) off += NL * 8u;      // (head, tail) of -exponent / 2 per link
+    out->expo = off; if (mode == PL_POWER || mode == PL_SHADOW || mode == PL_POWK) off += NL * 8u;   // (head, tail) of -exponent / 2 per link (PL_POWK: (phi, 0))
     off = (off + 7u) & ~7u;
     out->lo = off; if (xpos) off += NL * 8u;                                         // low parts of (tx_x, tx_y) per link (exact positions)
     out->tflat = off; if (fuse_obs) off += (unsigned)N * 24u;
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
     constexpr bool LISTS = (OPT & OPT_LISTS) != 0, SREC = (OPT & OPT_SREC) != 0, NT = (OPT & OPT_NT) != 0;
     constexpr bool XPOS = (OPT & OPT_XPOS) != 0;                   // float64 positions as (hi, lo) pairs: coord_diff (d2d_step_device.h)
     static_assert(!XPOS || HOT == 0, "the specialised kernels serve float32 positions (device-side resets)");
-    constexpr bool POWLAW = MODE == PL_POWER || MODE == PL_SHADOW;   // per-link exponents (rec_h, LDS expo[])
+    constexpr bool POWLAW = MODE == PL_POWER || MODE == PL_SHADOW || MODE == PL_POWK;   // per-link exponents (rec_h, LDS expo[])
+    // a zero distance shows as a non-finite gain (1 / d^2, and PL_POWK's reciprocal): no smallest-distance tracking per pair
+    constexpr bool NF_ONLY = MODE == PL_INV_SQUARE || MODE == PL_POWK;
     const int cfg_action_mode = HOT ? 0 : a.action_mode;
     const int cfg_col_mode = HOT ? 0 : a.col_mode;
     const int cfg_reward_fn = HOT ? 1 : a.reward_fn;
@@ -332,11 +334,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);                                                                 \
                 float g;                                                                                                \
                 if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];                                \
-                else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); } \
+                else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f), a.pow_k); if (!NF_ONLY) dmin = min(dmin, __float_as_int(d2)); } \
                 if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, (int)(j), i, 0u);              \
                 acc += (double)((o).z * g);                              /* simulator.py:97-101, linear mW */            \
             }
-            if (MODE == PL_INV_SQUARE || MODE == PL_POWER) {
+            if (MODE == PL_INV_SQUARE || MODE == PL_POWER || MODE == PL_POWK) {
                 // Empty slots are clamped onto the stand-in tuple at link[N] (zero power, 1e18 m away): fmaf(0, g, acc) leaves acc
                 // untouched, so the steps need no predication and their tuple reads go out together - four, then two, then one,
                 // each batch only if some lane of the wave still has a member (sorted: a lane's members are a prefix).
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                         const float d2 = fmaf(dx, dx, dy * dy);
                         float g;
                         if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];
-                        else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
+                        else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f), a.pow_k); if (!NF_ONLY) dmin = min(dmin, __float_as_int(d2)); }
                         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                         acc += (double)(o.z * g);                        // simulator.py:97-101, linear mW
                     }
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                             const float d2 = fmaf(dx, dx, dy * dy);
                             float g;
                             if (MODE == PL_TABLE) g = gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol];
-                            else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
+                            else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f), a.pow_k); if (!NF_ONLY) dmin = min(dmin, __float_as_int(d2)); }
                             if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                             acc += (double)(o.z * g);                    // simulator.py:97-101, linear mW
                             asm volatile("" ::"v"(o.w));                 // .w kept live: the tuple comes by ds_read_b128 (4 LDS cycles), not b96 (8)
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
                 const float d2 = fmaf(dx, dx, dy * dy);
                 float g;
                 if (MODE == PL_TABLE) g = same ? gtab[(size_t)(s.aux[j] & 0xFFFFFF) * a.table_pitch + tcol] : 0.0f;
-                else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f)); if (MODE != PL_INV_SQUARE) dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
+                else { g = pair_gain<MODE>(d2, POWLAW ? s.expo[j] : make_float2(-1.0f, 0.0f), a.pow_k); if (!NF_ONLY) dmin = same ? min(dmin, __float_as_int(d2)) : dmin; }
                 if (MODE == PL_SHADOW && same && d2 > a.shadow_d0sq) g *= shadow_factor(a, genv, j, i, 0u);
                 acc += same ? (double)(o.z * g) : 0.0;
             }
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         const float d2 = fmaf(dx, dx, dy * dy);
         float g;
         if (MODE == PL_TABLE) g = gtab[(size_t)(a.table_by_link ? i : txd) * a.table_pitch + tcol];
-        else { g = pair_gain<MODE>(d2, in.hh); if (MODE != PL_INV_SQUARE) dmin = min(dmin, __float_as_int(d2)); }
+        else { g = pair_gain<MODE>(d2, in.hh, a.pow_k); if (!NF_ONLY) dmin = min(dmin, __float_as_int(d2)); }
         float sig = me.z * g * rx_pl * rx_lin;                           // mW at the receiver, with rx gains
         float sig_snr = sig;
         if (MODE == PL_SHADOW && d2 > a.shadow_d0sq) {
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         cap_part += cap;
         // inverse-square gains: a zero distance in the walk shows up as 1/0 = inf in the accumulator (one test instead of a
         // min per interferer); the own link and the other path-loss modes track the smallest d2 itself
-        if (MODE == PL_INV_SQUARE) {
+        if (NF_ONLY) {
             // 1 / d^2 gains: a zero distance (own link: signal inf; an interferer: accumulator inf) always ends in a
             // non-finite SINR, so the common case is one compare and the cause is sorted out behind it
             if (UNLIKELY(!(fabsf(sinr_db) <= 3.0e38f))) {
@@ -850,7 +852,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool lists = a.walk == 2 && lpt > 0 && a.reward_fn != 3;
     const bool hot = a.action_mode == 0 && a.col_mode == 0 && a.n_fixed == 0 && a.act_stride == a.N && a.reward_fn == 1 &&
                      (a.walk == 0 || lists) && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 &&
-                     a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER) && !a.lpos_lo;
+                     a.mask_words > 0 && (mode == PL_INV_SQUARE || mode == PL_POWER || mode == PL_POWK) && !a.lpos_lo;
     const int hot_opt = (a.rec_uniform ? OPT_SREC : 0) | (a.nt_results ? OPT_NT : 0);
     const int xp = a.lpos_lo ? OPT_XPOS : 0;                   // float64 positions (d2d_set_positions_f64): the coord_diff kernels
     if (a.rollout) return launch_rollout(a, mode, (a.N % 64 ? (hot_opt & OPT_NT) | OPT_PAD : hot_opt) | xp, block_threads, stream);
@@ -860,7 +862,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     const bool hot2 = a.action_mode == 0 && a.col_mode == 0 && a.act_stride > 0 && a.reward_fn == 1 && a.write_table &&
                       a.walk == 0 && a.prefetch_envs > 0 && (a.ablate & 8191) == 0 && a.mask_words > 0 &&
                       a.fuse_obs == 4 && a.obs_q_per_row > 0 && !a.lpos_lo &&
-                      (mode == PL_INV_SQUARE || mode == PL_POWER);
+                      (mode == PL_INV_SQUARE || mode == PL_POWER || mode == PL_POWK);
 #define D2D_LAUNCH_1(...)                                                                                \
     do {                                                                                                 \
         if (lds > 48 * 1024)                                                                             \
@@ -903,6 +905,7 @@ hipError_t launch_step(const StepArgs& a, PlMode mode, int block_threads, hipStr
     switch (mode) {
         case PL_INV_SQUARE: D2D_LAUNCH(PL_INV_SQUARE); break;
         case PL_POWER: D2D_LAUNCH(PL_POWER); break;
+        case PL_POWK: D2D_LAUNCH(PL_POWK); break;
         case PL_TABLE: D2D_LAUNCH_COLD(PL_TABLE); break;          // the rollout specialisations exist for the power laws only
         case PL_SHADOW: D2D_LAUNCH_COLD(PL_SHADOW); break;
     }

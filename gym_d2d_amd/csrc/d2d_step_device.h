@@ -6,6 +6,9 @@
 
 namespace d2d {
 
+#define LIKELY(x) __builtin_expect(!!(x), 1)
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 typedef unsigned long long u64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -94,9 +97,61 @@ __device__ __forceinline__ float pow10_tenth(int p) {
     return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(fr), (int)ip);
 }
 
+// PL_POWK: (d^2)^(-n/2) for NP pairs at once, where every transmitter's exponent n lies within 1/2 of one integer k, the same for the
+// whole launch (path_loss.py:48-66 with ple near k; COST-Hata's slopes 3.6 - 4.4, path_loss.py:90-123: k = 4):
+//   (d^2)^(-k/2)   r = v_rcp(d^2) multiplied up: r, r r, (r r) r, ((r r) r) r; one v_rsq on top when k is odd - behind branches on k,
+//                  which is wave-uniform, taken once for the whole group of pairs;
+//   (d^2)^phi      exp2(phi log2(d^2)), phi = -(n - k) / 2 in [-1/4, 1/4]: v_log's relative ulp on log2(d^2) <= 20 is an absolute
+//                  3e-7 in the exponent at most (the general split, pow_neg_half, exists because at |h| ~ 2 the same ulp is 2.4e-6).
+// About 4e-7 relative in all.  Every kernel calls this with the same association of the products (NP = 1 for a single pair), so
+// they agree bit for bit.  A zero distance ends non-finite (inf from the reciprocal, or NaN from inf * 0), as with 1 / d^2.
+// KC != 0: k is known at compile time (the rollout kernel branches ONCE on the common case k == 4 and runs a copy of its pair section
+// without the tests on k: a taken branch costs a wave its instruction buffer); the operations, hence the bits, are the same.
+template <int NP, int KC = 0>
+__device__ __forceinline__ void pow_k_gains(const float (&d2)[NP], const float (&phi)[NP], int k_runtime, float (&g)[NP]) {
+    const int k = KC ? KC : k_runtime;
+    float r[NP], e[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        r[p] = __builtin_amdgcn_rcpf(d2[p]);
+        e[p] = __builtin_amdgcn_exp2f(phi[p] * __builtin_amdgcn_logf(d2[p]));
+    }
+    if (k >= 2) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) g[p] = r[p];
+    } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) g[p] = 1.0f;
+    }
+    if (k >= 4) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) g[p] *= r[p];
+    }
+    if (UNLIKELY(k >= 6)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) g[p] *= r[p];
+        if (k >= 8) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) g[p] *= r[p];
+        }
+    }
+    if (k & 1) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) g[p] *= __builtin_amdgcn_rsqf(d2[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] *= e[p];
+}
+
 template <int MODE>
-__device__ __forceinline__ float pair_gain(float d2, float2 h) {
+__device__ __forceinline__ float pair_gain(float d2, float2 h, int k = 0) {
     if (MODE == PL_INV_SQUARE) return __builtin_amdgcn_rcpf(d2);
+    if (MODE == PL_POWK) {
+        const float d[1] = {d2}, f[1] = {h.x};
+        float g[1];
+        pow_k_gains<1>(d, f, k, g);
+        return g[0];
+    }
     return pow_neg_half(d2, h);
 }
 
@@ -381,8 +436,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // rare arms (a reward rule's search when it fires, the sweep fallbacks): LLVM's loop vectoriser otherwise unrolls and widens
 // them into hundreds of instructions whose live values spill the hot path's scalars
 #define COLD_LOOP _Pragma("clang loop vectorize(disable) interleave(disable) unroll(disable)")
-#define LIKELY(x) __builtin_expect(!!(x), 1)
-#define UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 // kernel options (template parameter OPT of step_kernel / rollout_kernel)
 #define OPT_LISTS 1      /* generic kernels: per-RB member lists instead of the masks (StepArgs::walk == 2) */

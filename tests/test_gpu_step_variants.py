@@ -670,3 +670,67 @@ def test_rollout_kernel_zero_distance_own_link_matches_the_generic_kernels(nativ
         assert got['BUF_ENV_FLAGS'][env] & native.FLAG_ZERO_DISTANCE
     assert got['BUF_ENV_FLAGS'][3] == 0
     h.close()
+
+
+@pytest.mark.parametrize('ple', [1.2, 2.5, 3.0, 3.5, 4.4, 5.6, 7.9])
+def test_power_law_with_one_integer_near_every_exponent(native, ple):
+    """PL_POWK (round 6): every transmitter's exponent within 1/2 of ONE integer k -> (d^2)^(-k/2) by reciprocals and products times a
+    short exp2(phi log2 d^2), |phi| <= 1/4.  Every k from 1 to 8 (odd ones take a v_rsq on top), the rollout kernel (sparse RBs) and the
+    generic kernels (mask walk, all pairs): bit-identical among themselves, at the bar against the oracle."""
+    from gym_d2d_amd import path_loss as pl
+
+    class Ple(pl.LogDistancePathLoss):
+        def __init__(self, f):
+            super().__init__(f, ple=ple)
+    b, rbs, cues, dues = 10, 48, 64, 64
+    sim, pos, raw = _batch(b, rbs, cues, dues, rng_seed=int(ple * 10), path_loss_model=Ple)
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+
+    def run():
+        sim.step_arrays(raw)
+        return _snapshot(sim, native)
+    snaps = _variants(native, h, run)
+    _same(snaps)
+    assert snaps['auto']['BUF_ENV_FLAGS'].max() == 0
+    tx, rx, ty = default_links(cues, dues)
+    cols = orc.device_columns(*orc.device_configs(cues, dues)[1:])
+    ref = orc.full_step(pos.astype(np.float64), tx, rx, ty, raw, cols, orc.PathLossSpec('log_distance', 2.1, ple=ple), with_obs=False)
+    for f, buf in (('sinr_db', 'BUF_SINR_DB'), ('snr_db', 'BUF_SNR_DB'), ('capacity_mbps', 'BUF_CAPACITY')):
+        assert rel_err(snaps['auto'][buf], ref[f]) <= TOL, (ple, f, rel_err(snaps['auto'][buf], ref[f]))
+    h.close()
+
+
+def test_power_law_exponents_without_a_common_integer_keep_the_general_split(native, tmp_path):
+    """COST-Hata with a base station 60 m up (slope 33.3 -> exponent 3.33, k = 3) beside UEs at 1.5 m (4.375, k = 4): uplinks and
+    downlinks in one step have no common k, so the kernels keep the general split (pow_neg_half)."""
+    import json
+    from gym_d2d_amd import path_loss as pl
+    from gym_d2d_amd.simulator import Simulator
+    cfg = {'mbs': {'position': [0.0, 0.0], 'config': {'antenna_height_m': 60.0}}}
+    path = tmp_path / 'tall_bs.json'
+    path.write_text(json.dumps(cfg))
+    b, rbs, cues, dues = 6, 8, 12, 12
+    sim = Simulator(dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b, path_loss_model=pl.CostHataPathLoss, device_config_file=path))
+    rng = np.random.default_rng(4)
+    pos = random_layout(rng, b, cues, dues)
+    sim.set_positions(pos)
+    keys = [('mbs', f'cue{k:02d}') for k in range(4)] + [(f'cue{k:02d}', 'mbs') for k in range(4, cues)] + list(sim.devices.dues.keys())
+    sim.set_links(keys)
+    n = len(keys)
+    rb = rng.integers(0, rbs, (b, n)); rb[:, :4] = np.arange(4) % 2; rb[:, 4:cues] = 2 + rng.integers(0, rbs - 2, (b, cues - 4))   # up- and downlinks on disjoint RBs
+    pw = rng.integers(0, 20, (b, n))
+    h = sim.handle
+    h.set_obs_mode(native.OBS_TABLE)
+
+    def run():
+        sim.step_arrays(rb=rb, pwr=pw)
+        return _snapshot(sim, native)
+    snaps = _variants(native, h, run)
+    _same(snaps)
+    ids, cfgs, is_bs = orc.device_configs(cues, dues)
+    cfgs[0] = dict(cfgs[0], antenna_height_m=60.0)
+    cols = orc.device_columns(cfgs, is_bs)
+    ref = orc.step(pos.astype(np.float64), sim.link_tx, sim.link_rx, rb, pw, cols, orc.PathLossSpec('cost_hata', 2.1, area='suburban'))
+    assert rel_err(snaps['auto']['BUF_SINR_DB'], ref['sinr_db']) <= TOL
+    h.close()
