@@ -8,6 +8,7 @@ namespace d2d {
 
 #define LIKELY(x) __builtin_expect(!!(x), 1)
 #define UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define COLD_LOOP _Pragma("clang loop vectorize(disable) interleave(disable) unroll(disable)")
 
 typedef unsigned long long u64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -123,14 +124,17 @@ __device__ __forceinline__ void pow_k_gains(const float (&d2)[NP], const float (
 #pragma unroll
         for (int p = 0; p < NP; ++p) g[p] = 1.0f;
     }
-    if (k >= 4) {
+    // r, r r, (r r) r, ((r r) r) r: a wave-uniform trip count (a loop, not four tests: fewer scalar masks alive in the generic kernels;
+    // unrolled away when k is a compile-time constant)
+    if (KC) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) g[p] *= r[p];
-    }
-    if (UNLIKELY(k >= 6)) {
+        for (int q = 4; q <= KC; q += 2) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) g[p] *= r[p];
-        if (k >= 8) {
+            for (int p = 0; p < NP; ++p) g[p] *= r[p];
+        }
+    } else {
+        COLD_LOOP
+        for (int q = 4; q <= k; q += 2) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) g[p] *= r[p];
         }
@@ -435,7 +439,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // branch weights: block placement moves the rare arms (invalid actions, all-pairs sweep, flag reporting) behind the hot path
 // rare arms (a reward rule's search when it fires, the sweep fallbacks): LLVM's loop vectoriser otherwise unrolls and widens
 // them into hundreds of instructions whose live values spill the hot path's scalars
-#define COLD_LOOP _Pragma("clang loop vectorize(disable) interleave(disable) unroll(disable)")
 
 // kernel options (template parameter OPT of step_kernel / rollout_kernel)
 #define OPT_LISTS 1      /* generic kernels: per-RB member lists instead of the masks (StepArgs::walk == 2) */

@@ -49,8 +49,10 @@ def test_power_law_and_table_kernels_spill_no_scalars(kernels):
     Shannon / CueSinrShannon rewards, the table route and the member lists."""
     checked = 0
     for (mode, lpt, full, hot, opt), k in kernels.items():
-        if mode in (0, 1, 2) and lpt in (1, 2):
-            assert k['sgpr_spills'] == 0, ((mode, lpt, full, hot, opt), k)
+        if mode in (0, 1, 2, 4) and lpt in (1, 2):
+            # (PL_POWK, two links per thread sharing a workgroup with other envs - the coldest of its generic variants - keeps up to
+            # eight scalars in lanes: the uniform trip count and parity of k beside everything the general kernel holds)
+            assert k['sgpr_spills'] <= (8 if (mode, lpt, full) == (4, 2, 0) else 0), ((mode, lpt, full, hot, opt), k)
             checked += 1
     assert checked >= 24
 
@@ -64,7 +66,8 @@ def test_strided_and_shadowing_kernels_stay_within_a_few_lane_spills(kernels):
             # exact-position variant - the coldest kernel in the library - keeps 93 scalars in lanes, still none in memory)
             assert k['sgpr_spills'] < (100 if opt & 16 else 80), ((mode, lpt, full, hot, opt), k)
         elif lpt == 0:
-            assert k['sgpr_spills'] < 32, ((mode, lpt, full, hot, opt), k)
+            # (PL_POWK's strided variants hold the eight tests on k as scalar masks: a few lanes more)
+            assert k['sgpr_spills'] < (44 if mode == 4 else 32), ((mode, lpt, full, hot, opt), k)
 
 
 @pytest.fixture(scope='module')
@@ -84,8 +87,9 @@ def rollout_kernels(tmp_path_factory):
             out[tuple(int(x) for x in m.groups())] = {'vgpr': field('vgpr_count'), 'sgpr_spills': field('sgpr_spill_count'),
                                                       'vgpr_spills': field('vgpr_spill_count'), 'scratch': field('private_segment_fixed_size'),
                                                       'static_lds': field('group_segment_fixed_size')}
-    # 2 path-loss modes x (4 option sets x 2 links per thread + 2 padded variants + 6 exact-position variants: option bit 16)
-    assert len(out) == 32, sorted(out)
+    # 3 path-loss modes (1 / d^2, general power law, one-integer-k power law) x (4 option sets x 2 links per thread + 2 padded
+    # variants + 6 exact-position variants: option bit 16)
+    assert len(out) == 48, sorted(out)
     return out
 
 
@@ -98,13 +102,14 @@ def test_rollout_kernel_of_round5_keeps_full_occupancy_and_no_static_lds(rollout
         if key[1] & 16:                                  # exact positions (d2d_set_positions_f64): a fourth 16-byte row per link
             assert k['vgpr'] <= 80, (key, k)             # 6 waves per SIMD
         elif key[1] & 10:                                # scalar records (2) or a padded link count (8: one link per thread)
-            assert k['vgpr'] <= 64, (key, k)
+            # (the one-integer-k power law with a padded link count or two links per thread: 66 - 69, seven waves per SIMD)
+            assert k['vgpr'] <= (72 if key[0] == 4 and (key[1] & 8 or key[2] == 2) else 64), (key, k)
 
 
 def test_rollout_kernel_keeps_full_occupancy(kernels):
     """8 waves per SIMD (four 512-thread workgroups per CU) needs <= 64 VGPRs; the scalar-record variant holds the records in
     SGPRs and frees vector registers."""
-    for mode in (0, 1):
+    for mode in (0, 1, 4):
         for opt in (0, 2, 4, 6):
             k = kernels[(mode, 1, 1, 1, opt)]
             assert k['vgpr'] <= 64 and k['sgpr_spills'] == 0, (mode, opt, k)
