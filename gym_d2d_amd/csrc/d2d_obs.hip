@@ -11,8 +11,11 @@
 //     addresses (full 128-B lines, no partial-line read-modify-write); since round 4 the slab is FLAT (two
 //     consecutive pieces of 1024 float4, whatever the row length: obs_expand_flat_kernel), before that two whole rows;
 //   * row i is T shifted by 6 floats for columns [6, 6(i+1)) and unshifted after that; both boundaries are
-//     even, so every aligned float2 of the output maps to one aligned float2 of T: two conflict-free
-//     ds_read_b64 feed each global_store_dwordx4;
+//     even, so every aligned float2 of the output maps to one aligned float2 of T: two ds_read_b64 feed each
+//     global_store_dwordx4.  (Not conflict-free, as this comment claimed until round 5: the two halves of a float4 that
+//     straddles the shift boundary, and the lanes on either side of a row end, hit the same banks - SQ_LDS_BANK_CONFLICT /
+//     SQ_LDS_IDX_ACTIVE = 0.37, profiles/r5_pmc_stress_linear.json.  It costs nothing measurable: SQ_WAIT_INST_LDS is 0.04 %
+//     of the wave cycles of a kernel that runs at 0.977 of the box's best store-only kernel.)
 //   * stores are nontemporal (written once, never re-read by this kernel);
 //   * blockIdx is remapped so the chunks of one env share an XCD (its T stays in that XCD's L2).
 #include "d2d_internal.h"
