@@ -51,6 +51,12 @@
 namespace d2d {
 
 #define RO_SLOTS 8
+// ABLATION builds (D2D_BUILD_DEFINES="-DD2D_EXP_ABL=<bits>" python -m gym_d2d_amd.build; never shipped: results are WRONG, costs right):
+// 1 no input loads, 2 no result-plane stores, 4 no pair evaluation, 8 no reward epilogue, 16 no SINR arithmetic, 32 no action prefetch,
+// 64 no second barrier.  Round 6 (profiles/r6_rollout_kernel_ablation.jsonl): skeleton 9.2 us + pairs 4.9 + loads 3.8 + stores 2.2.
+#ifndef D2D_EXP_ABL
+#define D2D_EXP_ABL 0
+#endif
 // diagnostic builds: lane 0 of every wave stamps the shader clock at the phase boundaries (tools/phase_times.py)
 #if defined(D2D_STEP_ABLATE) && D2D_STEP_ABLATE
 #define RO_STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0)                                                            \
@@ -127,8 +133,9 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     // ---- prologue: the links' loads, issued before any LDS work or barrier (their latency overlaps pass 0)
     LinkRaw in[LPT];
     if (SREC && LPT == 2) {                                      // the thread's two actions: adjacent columns, one 8-byte load
+        if (D2D_EXP_ABL & 1) { in[0].act0 = (tid * 7919 + b * 13) % 5000; in[LPT - 1].act0 = (tid * 104729 + b * 17) % 5000; } else {
         const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, fresh((row + 2u * (unsigned)tid) * 4u)));
-        in[0].act0 = aa.x; in[LPT - 1].act0 = aa.y;
+        in[0].act0 = aa.x; in[LPT - 1].act0 = aa.y; }
     }
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
@@ -136,7 +143,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         if (SREC) {
             if (LPT == 1) in[u].act0 = *at(a.actions, fresh((row + (unsigned)i) * 4u));
             in[u].act1 = 0;
-            in[u].pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
+            if (D2D_EXP_ABL & 1) in[u].pos = make_float4((float)((i * 37 + b) % 997), (float)((i * 91 + b) % 983), (float)((i * 53 + b * 3) % 991) + 0.5f, (float)((i * 71 + b) % 977) + 0.5f);
+            else in[u].pos = *at(a.lpos, fresh((row + (unsigned)i) * 16u));
             in[u].plo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (XPOS) in[u].plo = *at(a.lpos_lo, fresh((row + (unsigned)i) * 16u));
         } else {
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         } else { RO_ST(at(a.rb_out, oe), rb[0]); RO_ST(at(a.pwr_out, oe), pwr[0]); }
     }
     RO_STAMP(3);
-    __syncthreads();
+    if (!(D2D_EXP_ABL & 64)) __syncthreads();
     RO_STAMP(4);
 
     // software prefetch of the action rows of the env the workgroup `prefetch_envs` later will own (see step_kernel).  (The position
@@ -261,7 +269,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         const int bq = b + a.prefetch_envs;
         const int bp = bq < a.B ? bq : a.B - 1;
         const unsigned op = fresh(((unsigned)bp * (SREC ? (unsigned)N : (unsigned)a.act_stride) + (unsigned)max(link_of(0) - n_fixed, 0)) * 4u);
-        if (LPT == 2) { const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, op)); pf = aa.x ^ aa.y; }
+        if (D2D_EXP_ABL & 32) pf = 0;
+        else if (LPT == 2) { const i32x2 aa = *reinterpret_cast<const i32x2*>(at(a.actions, op)); pf = aa.x ^ aa.y; }
         else pf = *at(a.actions, op);
     }
 
@@ -405,6 +414,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
                 RO_PAIR(3, o3) RO_PAIR(4, o4) RO_PAIR(5, o5)
                 asm volatile("" ::"v"(o3.w), "v"(o4.w), "v"(o5.w));
             }
+        } else if ((D2D_EXP_ABL & 4) && off[0] != 0x12345u) {
+            acc = 1e-12;
         } else {
             const f32x4 o0 = lds_get<f32x4>(L_LINK + off[0]), o1 = lds_get<f32x4>(L_LINK + off[1]), o2 = lds_get<f32x4>(L_LINK + off[2]),
                         o3 = lds_get<f32x4>(L_LINK + off[3]), o4 = lds_get<f32x4>(L_LINK + off[4]), o5 = lds_get<f32x4>(L_LINK + off[5]);
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             asm volatile("" ::"v"(o0.w), "v"(o1.w), "v"(o2.w), "v"(o3.w), "v"(o4.w), "v"(o5.w));   // .w kept live: ds_read_b128, not b96
         }
         // slots fill in arrival order: a seventh / eighth member exists for some lane of 2 in 3 / 1 in 4 waves
-        if (!POWK && __builtin_amdgcn_ballot_w64(off[6] != EMPTY) != 0ull) {
+        if (!POWK && !(D2D_EXP_ABL & 4) && __builtin_amdgcn_ballot_w64(off[6] != EMPTY) != 0ull) {
             const f32x4 o6 = lds_get<f32x4>(L_LINK + off[6]), o7 = lds_get<f32x4>(L_LINK + off[7]);
             if (off[7] != EMPTY) members = lds_get<unsigned>(L_CNT + rbc * 4u);
             RO_PAIR(6, o6) RO_PAIR(7, o7)
@@ -499,12 +510,16 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         const float sig = pz[u] * g_own * rx_pl * rx_lin;            // mW at the receiver, with rx gains
         const float accf = (float)acc;
         // interferers: no rx gains (simulator.py:100); the fma every kernel's `accf * rx_pl + noise` contracted to, spelled out
+#if D2D_EXP_ABL & 16
+        const float sinr_lin = sig + accf, sinr_db = sinr_lin * rx_pl, snr_db = sig * noise, sh = sinr_lin + 1.0f;
+#else
         const float sinr_lin = precise_div(sig, fmaf(accf, rx_pl, noise));
         const float sinr_db = 3.01029995663981195f * __builtin_amdgcn_logf(sinr_lin);                 // simulator.py:106-107
         const float snr_db = 3.01029995663981195f * __builtin_amdgcn_logf(precise_div(sig, noise));   // simulator.py:115
         const float u1p = 1.0f + sinr_lin, um1 = u1p - 1.0f;
         const float sh_big = __builtin_amdgcn_logf(u1p) * fast_div(sinr_lin, um1 == 0.0f ? 1.0f : um1);
         const float sh = um1 == 0.0f ? sinr_lin * 1.44269504088896340736f : sh_big;
+#endif
         const bool ok = sinr_db > sens;                              // simulator.py:123,149
         const float rate = ok ? sh : 0.0f;
         const float cap = ok ? bw_mhz * sh : 0.0f;                   // simulator.py:150-151
@@ -594,9 +609,43 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         *at(a.reward, fresh((row + (unsigned)i) * 4u)) = low ? -1.0f : sh_kept;
     }
 
+    // ---- reward, first half - ISSUED AHEAD OF THE RESULT STORES (round 6): the wave's capacity sum and its ticket are a chain of
+    // dependent long-latency steps (five DPP levels, two conversions, two LDS atomics, the ticket's round trip); behind the stores
+    // it was the last thing a wave did and every workgroup's exit waited for it - 1.3 us of the launch by ablation
+    // (profiles/r6_rollout_kernel_ablation.jsonl); in front of them it runs under the stores' issue.
+    // Barrier-free ticket reduction (see step_kernel): DPP wave sum, 32.32 fixed-point capacity total in LDS (the
+    // 64-bit integer sum does not depend on arrival order), the wave that draws the last ticket finishes the env
+    const int lane = tid & 63;
+    int ticket = 0;
+    if (!PAD) {
+    // one sum per GROUP OF 64 LINKS, each converted to fixed point on its own, with the roundings of the one-link-per-thread
+    // kernels' wave sum - a balanced tree over adjacent links: pairs, fours, ... 32 + 32.  LPT = 2: a lane's two links ARE
+    // the first level, the DPP steps the next four, and the two halves of the wave end as the two groups' sums (wave_sum_halves)
+    // - so the env's total has the same bits whatever LPT
+    unsigned long long fixed;
+    if (LPT == 2) {
+        float lo, hi;
+        wave_sum_halves(caps[0] + caps[LPT - 1], lo, hi);
+        fixed = to_fixed_32_32(lo) + to_fixed_32_32(hi);
+    } else fixed = to_fixed_32_32(wave_sum(shadow ? 0.0f : caps[0]));
+    asm volatile("" ::"v"(pf));                                      // the prefetched words are consumed here (no instruction)
+    // This wave's LDS atomics above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
+    // above it in the instruction stream.  The last wave's reads below stay behind its own ticket (acquire).
+    asm volatile("" ::: "memory");
+    if (lane == 0) {
+        // (a wave with a huge / non-finite capacity has raised bits 2 / 4 of flags[1]: the total is then not read, whatever
+        // v_cvt_u32_f32's saturation made of this sum)
+        __hip_atomic_fetch_add((D2D_LDS(unsigned long long)*)(0u), fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        ticket = __hip_atomic_fetch_add((D2D_LDS(int)*)(L_FLAGS + 8u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    }
+
     // ---- results: the thread's LPT links are adjacent elements of every plane and adjacent rows of the table
     {
         const unsigned o4 = fresh((row + (unsigned)link_of(0)) * 4u);
+        if ((D2D_EXP_ABL & 2) && sinrs[0] != 1.2345f) {
+        } else
         if (LPT == 2) {
             RO_ST(reinterpret_cast<f32x2*>(at(a.sinr_db, o4)), (f32x2{sinrs[0], sinrs[LPT - 1]}));
             RO_ST(reinterpret_cast<f32x2*>(at(a.snr_db, o4)), (f32x2{snrs[0], snrs[LPT - 1]}));
@@ -662,31 +711,8 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         RO_STAMP(8);
         return;
     }
-    // ---- reward: barrier-free ticket reduction (see step_kernel): DPP wave sum, 32.32 fixed-point capacity total in LDS (the
-    // 64-bit integer sum does not depend on arrival order), the wave that draws the last ticket finishes the env
-    const int lane = tid & 63;
-    // one sum per GROUP OF 64 LINKS, each converted to fixed point on its own, with the roundings of the one-link-per-thread
-    // kernels' wave sum - a balanced tree over adjacent links: pairs, fours, ... 32 + 32.  LPT = 2: a lane's two links ARE
-    // the first level, the DPP steps the next four, and the two halves of the wave end as the two groups' sums (wave_sum_halves)
-    // - so the env's total has the same bits whatever LPT
-    unsigned long long fixed;
-    if (LPT == 2) {
-        float lo, hi;
-        wave_sum_halves(caps[0] + caps[LPT - 1], lo, hi);
-        fixed = to_fixed_32_32(lo) + to_fixed_32_32(hi);
-    } else fixed = to_fixed_32_32(wave_sum(shadow ? 0.0f : caps[0]));
-    asm volatile("" ::"v"(pf));                                      // the prefetched words are consumed here (no instruction)
-    // This wave's LDS atomics above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
-    // above it in the instruction stream.  The last wave's reads below stay behind its own ticket (acquire).
-    asm volatile("" ::: "memory");
-    int ticket = 0;
-    if (lane == 0) {
-        // (a wave with a huge / non-finite capacity has raised bits 2 / 4 of flags[1]: the total is then not read, whatever
-        // v_cvt_u32_f32's saturation made of this sum)
-        __hip_atomic_fetch_add((D2D_LDS(unsigned long long)*)(0u), fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("" ::: "memory");
-        ticket = __hip_atomic_fetch_add((D2D_LDS(int)*)(L_FLAGS + 8u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    if ((D2D_EXP_ABL & 8) && caps[0] != 1.2345f) return;
+    // ---- reward, second half: the wave that drew the last ticket finishes the env
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (ticket == (TPE >> 6) - 1) {

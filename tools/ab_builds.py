@@ -39,7 +39,7 @@ def prepare(names):
         print('built', out.name)
 
 
-def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1, path_loss='log2'):
+def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1, path_loss='log2', positions='float32'):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools'))
     from gym_d2d_amd import _native
     _native.LIB_PATH = Path(lib).resolve()
@@ -71,6 +71,11 @@ def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1, path_loss='lo
         cols = p
     env.reset(seed=1)
     h = env.simulator.handle
+    if positions == 'float64':                   # the layout the sampler drew, moved off the float32 grid: the (hi, lo) kernels
+        import numpy as np
+        pos = env.simulator.positions().astype(np.float64)
+        pos[:, 1:] += np.random.default_rng(1).uniform(-1e-6, 1e-6, pos[:, 1:].shape)
+        env.simulator.set_positions(pos)
     h.set_export_actions(export)
     if walk >= 0:
         h.set_tuning(_native.TUNE_STEP_WALK, walk)
@@ -78,13 +83,13 @@ def one(lib, workload, export=True, mode='table', walk=-1, lpt=-1, path_loss='lo
         h.set_tuning(_native.TUNE_STEP_LPT, lpt)
     act = torch.randint(0, r * 21, (64, b, cols), device=env.device, dtype=torch.int32)
     t = [timed(h, act, 32) for _ in range(15)]
-    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'path_loss': path_loss, 'obs': mode, 'walk': walk, 'lpt': lpt, 'export_rb_pwr': int(export), 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
+    print(json.dumps({'build': Path(lib).stem, 'workload': workload, 'path_loss': path_loss, 'positions': positions, 'obs': mode, 'walk': walk, 'lpt': lpt, 'export_rb_pwr': int(export), 'median_us': round(statistics.median(t), 2), 'min_us': round(min(t), 2)}))
 
 
-def run(workload, passes, export=True, mode='table', walk=-1, lpt=-1, path_loss='log2'):
+def run(workload, passes, export=True, mode='table', walk=-1, lpt=-1, path_loss='log2', positions='float32'):
     for k in range(passes):
         for lib in sorted(LIBS.glob('*.so')):
-            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload, '--mode', mode, '--walk', str(walk), '--lpt', str(lpt), '--path-loss', path_loss] + ([] if export else ['--no-export']),
+            r = subprocess.run([sys.executable, __file__, 'one', str(lib), '--workload', workload, '--mode', mode, '--walk', str(walk), '--lpt', str(lpt), '--path-loss', path_loss, '--positions', positions] + ([] if export else ['--no-export']),
                                capture_output=True, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             print(line[-1] if line else f'{lib.name}: failed {r.stderr[-300:]}', flush=True)
@@ -100,11 +105,12 @@ if __name__ == '__main__':
     ap.add_argument('--walk', type=int, default=-1, help='D2D_TUNE_STEP_WALK (-1 = the library default)')
     ap.add_argument('--lpt', type=int, default=-1, help='D2D_TUNE_STEP_LPT (-1 = the library default)')
     ap.add_argument('--path-loss', default='log2', choices=['log2', 'cost_hata'], help='log-distance with exponent 2 (1 / d^2 kernels) or COST-Hata (power-law kernels)')
+    ap.add_argument('--positions', default='float32', choices=['float32', 'float64'], help='float64: host-uploaded layout off the float32 grid (d2d_set_positions_f64, OPT_XPOS kernels)')
     ap.add_argument('--no-export', action='store_true', help='d2d_set_export_actions(0): no decoded rb / pwr planes')
     a = ap.parse_args()
     if a.what == 'prepare':
         prepare(a.names)
     elif a.what == 'run':
-        run(a.workload, a.passes, not a.no_export, a.mode, a.walk, a.lpt, a.path_loss)
+        run(a.workload, a.passes, not a.no_export, a.mode, a.walk, a.lpt, a.path_loss, a.positions)
     else:
-        one(a.names[0], a.workload, not a.no_export, a.mode, a.walk, a.lpt, a.path_loss)
+        one(a.names[0], a.workload, not a.no_export, a.mode, a.walk, a.lpt, a.path_loss, a.positions)
