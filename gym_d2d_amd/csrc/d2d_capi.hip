@@ -194,10 +194,12 @@ int refresh_tables(d2d_handle* h) {
         // keeps the general split (pow_neg_half)
         h->pow_k = 0;
         if (!all_two && h->N > 0) {
-            const int k = (int)std::lround(h->expo[h->host_tx[0]]);
-            bool ok = k >= 1 && k <= 8;
-            for (int i = 0; i < h->N && ok; ++i) ok = std::fabs(h->expo[h->host_tx[i]] - (double)k) <= 0.5;
-            if (ok) { h->mode = d2d::PL_POWK; h->pow_k = k; }
+            const int k0 = (int)std::lround(h->expo[h->host_tx[0]]);
+            for (int k : {k0, k0 + 1, k0 - 1}) {              // (link 0's exponent may sit at the edge of the band the others share)
+                bool ok = k >= 1 && k <= 8;
+                for (int i = 0; i < h->N && ok; ++i) ok = std::fabs(h->expo[h->host_tx[i]] - (double)k) <= 0.5;
+                if (ok) { h->mode = d2d::PL_POWK; h->pow_k = k; break; }
+            }
         }
     }
     // Per-link records, 3 rows of [Nmax] x 16 B (layout: d2d_internal.h).  tx-side columns by the link's tx device,
