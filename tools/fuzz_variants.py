@@ -45,15 +45,20 @@ def main():
         b = int(rng.integers(1, 20)) if cues + dues > 600 else int(rng.integers(1, 70))
         reward = int(rng.integers(1, 4))
         linear = (cues + dues <= 128 and rng.random() < 0.5) or (cues + dues <= 400 and rng.random() < 0.25)   # beyond 128 links: the stand-alone expansion
-        model = rng.choice(['log2', 'ple'])
+        model = rng.choice(['log2', 'ple', 'ple', 'hata'])
         cfg = dict(num_rbs=rbs, num_cues=cues, num_due_pairs=dues, num_envs=b)
         if model == 'ple':
             from gym_d2d_amd.path_loss import LogDistancePathLoss
+            # round 6: any exponent - PL_POWK for every k in 1 .. 8 (odd ones take a v_rsq on top), the general split beyond 8.5
+            ple = float(rng.choice([1.2, 2.5, 3.0, 3.3, 3.5, 4.4, 5.6, 7.9, 9.1]))
 
             class Ple(LogDistancePathLoss):
                 def __init__(self, f):
-                    super().__init__(f, ple=3.3)
+                    super().__init__(f, ple=ple)
             cfg['path_loss_model'] = Ple
+        elif model == 'hata':
+            from gym_d2d_amd.path_loss import CostHataPathLoss
+            cfg['path_loss_model'] = CostHataPathLoss
         sim = Simulator(cfg)
         pos = random_layout(rng, b, cues, dues)
         if rng.random() < 0.3 and cues + dues > 8:
@@ -64,6 +69,10 @@ def main():
                 e, i, j = int(rng.integers(0, b)), int(rng.integers(1, d)), int(rng.integers(1, d))
                 if i != j:
                     pos[e, i] = pos[e, j] + (rng.uniform(0.2, 3.0) * np.array([np.cos(k := rng.uniform(0, 6.283)), np.sin(k)])).astype(np.float32)
+        if rng.random() < 0.3:
+            # round 6: a float64 layout off the float32 grid (d2d_set_positions_f64): the hi + lo variants of every kernel
+            pos = pos.astype(np.float64)
+            pos[:, 1:] += rng.uniform(-1e-5, 1e-5, pos[:, 1:].shape)
         sim.set_positions(pos)
         sim.set_links(sim.default_link_keys())
         p = sim.config.num_pwr_actions
