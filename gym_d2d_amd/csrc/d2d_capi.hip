@@ -185,6 +185,15 @@ int refresh_tables(d2d_handle* h) {
         cols[5 * D + d] = (float)(1e-6 * h->bw[d]);
         cols[6 * D + d] = h->mode == d2d::PL_TABLE ? 2.0f : (float)h->expo[d];
         if (h->mode != d2d::PL_TABLE && h->expo[d] != 2.0) all_two = false;
+        // The kernels work in linear float32 (mW and plain gain factors): a link-budget constant beyond about +-300 dB
+        // (COST-Hata's mobile-height correction applied to a receiving antenna above ~100 m, path_loss.py:105-112) leaves that range
+        // and would surface as inf / NaN results.  Refused here, by name, instead.
+        for (int c = 0; c < 4; ++c) {
+            const float v = cols[c * D + d];
+            if (!(v >= 1.0e-30f && v <= 1.0e30f))
+                return fail(D2D_ERR_UNSUPPORTED, "device " + std::to_string(d) + ": link-budget constant " + std::to_string(c) +
+                                                 " (tx_lin, rx_pl, rx_lin, noise_mw) is outside the float32 linear range 1e-30 .. 1e30 (a term beyond +-300 dB)");
+        }
     }
     if (h->mode != d2d::PL_TABLE && h->mode != d2d::PL_SHADOW) {
         h->mode = all_two ? d2d::PL_INV_SQUARE : d2d::PL_POWER;

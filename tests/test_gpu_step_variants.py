@@ -734,3 +734,21 @@ def test_power_law_exponents_without_a_common_integer_keep_the_general_split(nat
     ref = orc.step(pos.astype(np.float64), sim.link_tx, sim.link_rx, rb, pw, cols, orc.PathLossSpec('cost_hata', 2.1, area='suburban'))
     assert rel_err(snaps['auto']['BUF_SINR_DB'], ref['sinr_db']) <= TOL
     h.close()
+
+
+def test_link_budget_constants_outside_the_float32_range_are_refused(native, tmp_path):
+    """The kernels work in linear float32: COST-Hata's mobile-height correction (path_loss.py:105-112) applied to a RECEIVING base
+    station 250 m up is a -734 dB term, 10^73 as a factor.  The library says so (D2D_ERR_UNSUPPORTED, naming the device) instead of
+    returning inf / NaN planes; the same model with the station at 60 m runs (test above)."""
+    import json
+    from gym_d2d_amd import path_loss as pl
+    from gym_d2d_amd.simulator import Simulator
+    path = tmp_path / 'very_tall_bs.json'
+    path.write_text(json.dumps({'mbs': {'position': [0.0, 0.0], 'config': {'antenna_height_m': 250.0}}}))
+    sim = Simulator(dict(num_rbs=4, num_cues=3, num_due_pairs=3, num_envs=2, path_loss_model=pl.CostHataPathLoss, device_config_file=path))
+    sim.set_positions(random_layout(np.random.default_rng(1), 2, 3, 3))
+    sim.set_links(sim.default_link_keys())
+    with pytest.raises(native.NativeError, match='float32 linear range') as err:
+        sim.step_arrays(np.zeros((2, 6), dtype=np.int32))
+    assert err.value.code == native.ERR_UNSUPPORTED
+    sim.handle.close()
