@@ -175,7 +175,7 @@ def test_host_reset_reproduces_python_random_stream():
     env.simulator.handle.close()
 
 
-@pytest.mark.parametrize('script', ['simple_env.py', 'custom_path_loss.py', 'saving_loading_device_config.py', 'vec_env.py'])
+@pytest.mark.parametrize('script', ['simple_env.py', 'custom_path_loss.py', 'array_path_loss.py', 'saving_loading_device_config.py', 'vec_env.py'])
 def test_examples_run(script):
     r = subprocess.run([sys.executable, str(ROOT / 'examples' / script)], capture_output=True, text=True, timeout=600,
                        env={**os.environ, 'PYTHONPATH': str(ROOT)})
