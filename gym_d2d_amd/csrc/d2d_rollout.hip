@@ -66,9 +66,9 @@ namespace d2d {
 #endif
 #define RO_ST(ptr, val) do { if (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 
-// LDS of one env (byte offsets; StepLds): 0 sum (u64) ... 60 dump (u16) | 64 flags[4]: env flags, reward bits, ticket, pool count
+// LDS of one env (byte offsets; StepLds): 0 ... 59 unused, 60 dump (u16) | 64 flags[4]: env flags, reward bits, ticket, pool count
 // | 80 link[N + 1] tuples | expo[N + 1] (power law) | lo[N + 1] (exact positions) | slots[R + 1] (8 x u16) | cnt[R + 1] | pool[N] (rb, link) | 16 wave sums
-// (padded link counts) | low[N + 1] (CueSinrShannon).  With two links per thread the region from 80 on becomes the env's table image.
+// (the reward's group sums) | low[N + 1] (CueSinrShannon).  With two links per thread the region from 80 on becomes the env's table image.
 void rollout_lds_layout(int N, int R, int mode, int reward_fn, int xpos, StepLds* out) {
     std::memset(out, 0, sizeof(*out));
     unsigned off = LDS_HEAD_BYTES + ((unsigned)N + 1u) * 16u;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
             if (XPOS) lds_put<f32x2>(L_LO + (EMPTY >> 1), f32x2{0.0f, 0.0f});
         }
         if (tid < 5) lds_put<u32x4>((unsigned)tid * 16u, u32x4{0u, 0u, 0u, 0u});          // sum, dump, flags[4]: 80 bytes
-        if (PAD && tid >= 8 && tid < 12) lds_put<u32x4>(L_RED + (unsigned)(tid - 8) * 16u, u32x4{0u, 0u, 0u, 0u});
+        if (tid >= 8 && tid < 12) lds_put<u32x4>(L_RED + (unsigned)(tid - 8) * 16u, u32x4{0u, 0u, 0u, 0u});   // the 16 group sums of the reward
     }
     // nothing that consumes a loaded value may be scheduled above this barrier (the wave would sit on the HBM round trip
     // before pass 0 instead of behind it)
@@ -526,16 +526,14 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
         caps[u] = cap; rates[u] = rate; sinrs[u] = sinr_db; snrs[u] = snr_db;
 
         // per-lane rarities behind ONE wave-uniform branch: SystemCapacity's -1 rule (reward_fn.py:29-41: I am a non-D2D link whose
-        // capacity is <= min_capacity and some D2D link shares my RB), a non-finite SINR / zero distance, a capacity too large for
-        // the fixed-point sum (64 lanes x 3e7 stays below the 4e9 a 32.32 value holds)
+        // capacity is <= min_capacity and some D2D link shares my RB), a non-finite SINR / zero distance
         const bool rule = capacity_reward && type != LINK_SIDELINK && cap <= a.reward_param;
         // ShannonRewardFunction (reward_fn.py:52-57) is per link: log2(1 + SINR), or -1 below the threshold.  (A plain 4-byte store
         // per link, in here: the value would otherwise stay live across the other link's evaluation - a 65th VGPR.)
         if (shannon_reward) *at(a.reward, fresh((row + (unsigned)i) * 4u)) = sinr_db >= a.reward_param ? sh : -1.0f;
         if (LPT == 1) sh_kept = sh;
         const bool nonfinite = NF_ONLY ? !(fabsf(sinr_db) <= 3.0e38f) : (dmin == 0 || !(fabsf(sinr_db) <= 3.0e38f));
-        const bool huge = !(cap <= 3.0e7f);
-        if (UNLIKELY(__builtin_amdgcn_ballot_w64(rule | nonfinite | huge) != 0ull)) {
+        if (UNLIKELY(__builtin_amdgcn_ballot_w64(rule | nonfinite) != 0ull)) {
             if (rule) {
                 bool hit = false;
                 const auto sidelink = [&](unsigned j) { return ((a.side_words[j >> 5] >> (j & 31u)) & 1u) != 0u; };
@@ -567,9 +565,6 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
                 if (!(fabsf(sinr_db) <= 3.0e38f)) my_flags |= FLAG_NON_FINITE;
             }
             if (my_flags) lds_atomic_or(L_FLAGS, my_flags);
-            // a non-finite (or absurdly large) capacity cannot go through the fixed-point accumulator: the env's reward is then what
-            // a float sum gives - inf, or NaN once a NaN is among the parts
-            if (huge && !PAD) lds_atomic_or(L_FLAGS + 4u, cap != cap ? 4 : 2);   // (padded: a float sum, which carries inf / NaN itself)
         }
         RO_STAMP(5 + u);
     }
@@ -610,35 +605,36 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     }
 
     // ---- reward, first half - ISSUED AHEAD OF THE RESULT STORES (round 6): the wave's capacity sum and its ticket are a chain of
-    // dependent long-latency steps (five DPP levels, two conversions, two LDS atomics, the ticket's round trip); behind the stores
-    // it was the last thing a wave did and every workgroup's exit waited for it - 1.3 us of the launch by ablation
+    // dependent long-latency steps (five DPP levels, an LDS write, the ticket's round trip); behind the stores it was the last thing
+    // a wave did and every workgroup's exit waited for it - 1.3 us of the launch by ablation
     // (profiles/r6_rollout_kernel_ablation.jsonl); in front of them it runs under the stores' issue.
-    // Barrier-free ticket reduction (see step_kernel): DPP wave sum, 32.32 fixed-point capacity total in LDS (the
-    // 64-bit integer sum does not depend on arrival order), the wave that draws the last ticket finishes the env
+    // Barrier-free ticket reduction (see step_kernel): DPP wave sum into the wave's own slot, the wave that draws the last ticket
+    // finishes the env
     const int lane = tid & 63;
     int ticket = 0;
     if (!PAD) {
-    // one sum per GROUP OF 64 LINKS, each converted to fixed point on its own, with the roundings of the one-link-per-thread
-    // kernels' wave sum - a balanced tree over adjacent links: pairs, fours, ... 32 + 32.  LPT = 2: a lane's two links ARE
-    // the first level, the DPP steps the next four, and the two halves of the wave end as the two groups' sums (wave_sum_halves)
-    // - so the env's total has the same bits whatever LPT
-    unsigned long long fixed;
+    // one float sum per GROUP OF 64 LINKS, with the roundings of the one-link-per-thread kernels' wave sum - a balanced tree over
+    // adjacent links: pairs, fours, ... 32 + 32.  LPT = 2: a lane's two links ARE the first level, the DPP steps the next four, and
+    // the two halves of the wave end as the two groups' sums (wave_sum_halves).  Every wave parks its group sums in its own slots of
+    // red[16] (no atomic: nobody else writes them) and then takes a ticket; the wave that draws the last one adds the slots in INDEX
+    // order - the generic kernels' `(v.x + v.y) + (v.z + v.w)` per four - so the env's total has the same bits whatever LPT, whatever
+    // the order the waves arrive in, and whatever kernel reduced it.  (Until round 6 this was a 32.32 fixed-point atomic sum: exact,
+    // hence order-free too, but truncating below 2^-32 Mbps per wave - a last-digit difference from the float sums of envs that share
+    // a workgroup once capacities are 1e-6 Mbps, found by the fuzzer at a path-loss exponent of 5.6 - and two conversions, a 64-bit
+    // atomic and an overflow guard per link dearer.)
     if (LPT == 2) {
         float lo, hi;
         wave_sum_halves(caps[0] + caps[LPT - 1], lo, hi);
-        fixed = to_fixed_32_32(lo) + to_fixed_32_32(hi);
-    } else fixed = to_fixed_32_32(wave_sum(shadow ? 0.0f : caps[0]));
+        if (lane == 0) lds_put<f32x2>(L_RED + (unsigned)(tid >> 6) * 8u, f32x2{lo, hi});
+    } else {
+        const float wsum = wave_sum(shadow ? 0.0f : caps[0]);
+        if (lane == 0) lds_put<float>(L_RED + (unsigned)(tid >> 6) * 4u, wsum);
+    }
     asm volatile("" ::"v"(pf));                                      // the prefetched words are consumed here (no instruction)
-    // This wave's LDS atomics above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
+    // This wave's LDS writes above precede its ticket in the LDS queue (in order per wave); the compiler barrier keeps them
     // above it in the instruction stream.  The last wave's reads below stay behind its own ticket (acquire).
     asm volatile("" ::: "memory");
-    if (lane == 0) {
-        // (a wave with a huge / non-finite capacity has raised bits 2 / 4 of flags[1]: the total is then not read, whatever
-        // v_cvt_u32_f32's saturation made of this sum)
-        __hip_atomic_fetch_add((D2D_LDS(unsigned long long)*)(0u), fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("" ::: "memory");
-        ticket = __hip_atomic_fetch_add((D2D_LDS(int)*)(L_FLAGS + 8u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    if (lane == 0) ticket = __hip_atomic_fetch_add((D2D_LDS(int)*)(L_FLAGS + 8u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
     // ---- results: the thread's LPT links are adjacent elements of every plane and adjacent rows of the table
@@ -717,10 +713,16 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const StepArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (ticket == (TPE >> 6) - 1) {
         // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone on a violation
-        const unsigned long long tot = __hip_atomic_fetch_add((D2D_LDS(unsigned long long)*)(0u), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // an LDS read that cannot be hoisted
-        const float total = (float)tot * 2.3283064365386963e-10f;
+        float total = 0.0f;
+        for (int w = 0; w < (N + 255) >> 8; ++w) {                   // (atomic loads: LDS reads that cannot be hoisted above the ticket)
+            const float v0 = __hip_atomic_load((D2D_LDS(float)*)(L_RED + (unsigned)w * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const float v1 = __hip_atomic_load((D2D_LDS(float)*)(L_RED + (unsigned)w * 16u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const float v2 = __hip_atomic_load((D2D_LDS(float)*)(L_RED + (unsigned)w * 16u + 8u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const float v3 = __hip_atomic_load((D2D_LDS(float)*)(L_RED + (unsigned)w * 16u + 12u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            total += (v0 + v1) + (v2 + v3);
+        }
         const int viol = __hip_atomic_fetch_or((D2D_LDS(int)*)(L_FLAGS + 4u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const float r = (viol & 1) ? -1.0f : ((viol & 4) ? __int_as_float(0x7FC00000) : ((viol & 2) ? __int_as_float(0x7F800000) : total * a.inv_n));
+        const float r = (viol & 1) ? -1.0f : total * a.inv_n;        // (an inf / NaN capacity rides through the float sum by itself)
         if (!capacity_reward) {
             // per-link rewards are out already; the ticket only decides who publishes the env's flags
         } else if (a.reward_env) {                                     // D2D_REWARD_PER_ENV: the scalar once, not N copies

@@ -37,8 +37,9 @@
 //     latency chains, store-instruction counts or the walk's imbalance (profiles/r3_ab_*.jsonl);
 //   * all arithmetic is in the LINEAR domain (mW): sinr = S / (I + N) with one 10*log10 at the end; the literal
 //     dB-domain transcription cannot hold 1e-5 relative in fp32 (hard parts);
-//   * the capacity sum is a DPP wave reduction + an order-independent cross-wave sum (32.32 fixed point in the barrier-free
-//     epilogue of the one-env-per-workgroup kernels, a fixed-order float sum elsewhere): run-to-run deterministic;
+//   * the capacity sum is a DPP wave reduction into the wave's own LDS slot + a fixed-order float sum of the slots (by the wave that
+//     draws the last ticket in the barrier-free epilogue of the one-env-per-workgroup kernels, behind one barrier elsewhere): the
+//     same bits on every path, run-to-run deterministic;
 //   * small envs (N <= 128) expand their LinearObs block inside this launch: the workgroup's envs are one contiguous region,
 //     walked in passes of blockDim consecutive float4 with a per-lane (env, row, column) position that is advanced, not
 //     recomputed, and the LDS reads of the next pass issued ahead of the store of this one (round 4: 15.7 -> 13.4 us at
@@ -595,9 +596,8 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
 
     // ---- pass 3: reward
     if (FULL && cfg_reward_fn != 3) {
-        // No barrier: every wave publishes its part with LDS atomics, takes a ticket, and the wave that draws the last
-        // ticket (all other waves' atomics precede their ticket in LDS order) finishes the env.  The capacity sum is
-        // accumulated in 2^-32 Mbps fixed point, so the 64-bit integer total does not depend on arrival order.
+        // No barrier: every wave publishes its part in LDS, takes a ticket, and the wave that draws the last ticket (all other
+        // waves' LDS operations precede their ticket in LDS order) finishes the env.
         const int lane = tid & 63;
         if (cfg_reward_fn == 2) {                                                          // reward_fn.py:52-57
 #pragma unroll
@@ -605,11 +605,11 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         }
         int ticket = 0;
         if (cfg_reward_fn == 1) {
+            // the wave's sum into ITS slot of red[16] (no atomic: nobody else writes it); the wave that draws the last ticket adds the
+            // slots in index order, exactly as the barrier path below does - one reduction, the same bits, whichever path and
+            // whatever order the waves arrive in.  (A 32.32 fixed-point atomic total until round 6: see csrc/d2d_rollout.hip.)
             const float wsum = wave_sum(cap_part);
-            // a non-finite wave sum (zero distance: inf capacity) cannot go through the fixed-point accumulator: the env's
-            // reward is then what the generic path's float sum gives - inf, or NaN once a NaN is among the parts
-            if (UNLIKELY(!(wsum <= 4.0e9f))) atomicOr(&s.flags[1], wsum != wsum ? 4 : 2);
-            else if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(s.red), to_fixed_32_32(wsum));
+            if (lane == 0) __hip_atomic_store(&s.red[tid >> 6], wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (violated) atomicOr(&s.flags[1], 1);
         }
         // consume the prefetched word here, at the end: an empty asm that names the register keeps the load alive and costs
@@ -624,10 +624,16 @@ __global__ __launch_bounds__(1024) void step_kernel(const StepArgs a) {
         if (ticket == (TPE >> 6) - 1) {
             if (cfg_reward_fn == 1) {
                 // SystemCapacityRewardFunction, reward_fn.py:27-44: mean capacity, or -1 for everyone on a violation
-                const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long*>(s.red), 0ull);   // LDS read that cannot be hoisted
-                const float total = (float)tot * 2.3283064365386963e-10f;
+                float total = 0.0f;
+                for (int w = 0; w < (TPE + 255) >> 8; ++w) {                   // (atomic loads: LDS reads that cannot be hoisted above the ticket)
+                    const float v0 = __hip_atomic_load(&s.red[4 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const float v1 = __hip_atomic_load(&s.red[4 * w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const float v2 = __hip_atomic_load(&s.red[4 * w + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const float v3 = __hip_atomic_load(&s.red[4 * w + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    total += (v0 + v1) + (v2 + v3);
+                }
                 const int viol = atomicOr(&s.flags[1], 0);
-                const float r = (viol & 1) ? -1.0f : ((viol & 4) ? __int_as_float(0x7FC00000) : ((viol & 2) ? __int_as_float(0x7F800000) : total * a.inv_n));
+                const float r = (viol & 1) ? -1.0f : total * a.inv_n;          // (an inf / NaN capacity rides through the float sum by itself)
                 // N = LPT * blockDim is a multiple of 64: the row goes out as 16-byte stores
                 if (a.reward_env) {                                            // D2D_REWARD_PER_ENV: the scalar once, not N copies
                     if (lane == 0) a.reward_env[b] = r;

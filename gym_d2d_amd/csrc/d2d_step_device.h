@@ -54,15 +54,6 @@ __device__ __forceinline__ void wave_sum_halves(float v, float& lo, float& hi) {
     hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// v * 2^32 truncated to an integer, for 0 <= v < 2^32: whole part and fraction converted separately (two v_cvt_u32_f32)
-// instead of the generic float -> u64 sequence; the same value (the scaling by 2^32 is exact).
-__device__ __forceinline__ unsigned long long to_fixed_32_32(float v) {
-    const unsigned hi = (unsigned)v;
-    const float frac = v - (float)hi;
-    const unsigned lo = (unsigned)(frac * 4294967296.0f);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // (d^2)^h for h = -e/2 given as a head + tail pair (h.x: the 12 leading bits of h, so that h.x * exponent is exact; h.y = h - h.x,
 // both built by the host in double precision, d2d_capi.hip::refresh_tables), to ~2.5e-7 relative.  log2 of the mantissa and the
 // integer exponent are handled separately so the error does not scale with |log2(d^2)| (a plain exp2(h*log2(x)) loses ~2e-6), and

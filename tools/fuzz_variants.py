@@ -143,11 +143,6 @@ def main():
                 if name == 'BUF_REWARD' and reward == 1 and tune[nat.TUNE_STEP_LPT] == 2 and cues + dues <= 1024:
                     # two links per thread add the capacities in another order than one link per thread: last-bit differences
                     ok = np.allclose(got[name], r, rtol=2e-6, atol=0.0, equal_nan=True)
-                elif name == 'BUF_REWARD' and reward == 1:
-                    # SystemCapacity's env total: a float sum where envs share a workgroup, a 32.32 fixed-point sum where an env owns
-                    # one.  The two agree bit for bit while the wave sums are >= 2^-8 Mbps; below (exponents of 5 and more: capacities
-                    # of 1e-6 Mbps) the fixed-point side truncates at 2^-32 Mbps per wave - 3.6e-12 on the reward at most
-                    ok = np.array_equal(got[name], r, equal_nan=True) or np.allclose(got[name], r, rtol=0.0, atol=1e-11, equal_nan=True)
                 elif name == 'BUF_ENV_FLAGS':
                     ok = np.array_equal(got[name], r)
                 else:
