@@ -113,4 +113,4 @@ def test_rollout_kernel_keeps_full_occupancy(kernels):
         for opt in (0, 2, 4, 6):
             k = kernels[(mode, 1, 1, 1, opt)]
             assert k['vgpr'] <= 64 and k['sgpr_spills'] == 0, (mode, opt, k)
-        assert kernels[(mode, 1, 1, 1, 2)]['vgpr'] < kernels[(mode, 1, 1, 1, 0)]['vgpr']
+        assert kernels[(mode, 1, 1, 1, 2)]['vgpr'] <= kernels[(mode, 1, 1, 1, 0)]['vgpr']
